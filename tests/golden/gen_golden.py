@@ -1,0 +1,513 @@
+#!/usr/bin/env python3
+"""Golden-vector generator: runs the *Python reference* (drsagitn/sejonggo, mounted read-only at
+/root/reference) in THIS container and records inputs + expected outputs as small .npz fixtures.
+
+The reference cannot travel to the GPU box, so everything the parity tests need is captured here
+as plain arrays (np.load(allow_pickle=False) reads them).  Run from anywhere:
+
+    PYTHONDONTWRITEBYTECODE=1 python3 tests/golden/gen_golden.py            # all fixtures
+    PYTHONDONTWRITEBYTECODE=1 python3 tests/golden/gen_golden.py --only sym # one family
+
+Recipe: cwd is a scratch dir (so the reference's logconfig.json is not picked up),
+`sgfsave` and `model` are stubbed in sys.modules (they need sgfmill/h5py/TensorFlow, absent here),
+conf[...] is set BEFORE play/self_play/nomodel_self_play are imported (constants are captured at
+import), one subprocess per board size.  RNG streams of the reference (np.random.choice,
+np.random.dirichlet, random.choice) cannot be matched by a GPU implementation, so the harness
+replaces them with recorded draws: the draws are part of the fixture ("RNG stream parity unpinned;
+draws injected").  The multiprocessing Pool / SimpleQueue of simulation_workers.py are replaced by
+in-process fakes whose results arrive in launch order (one legal interleaving of the reference's
+racy pool); pickling is emulated with deepcopy / np.copy.
+"""
+import argparse
+import hashlib
+import os
+import re
+import struct
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+
+
+# ----------------------------------------------------------------------------------------------
+# child-process side: everything below runs with the reference importable
+# ----------------------------------------------------------------------------------------------
+def _setup_reference(size, sims, energy, komi=5.5):
+    import types
+    sys.setrecursionlimit(20000)
+    sys.path.insert(0, REF)
+    sys.path.insert(0, REPO)
+    sgfsave = types.ModuleType("sgfsave")
+    for n in ("save_self_play_data", "save_game_data", "save_game_sgf", "save_file"):
+        setattr(sgfsave, n, lambda *a, **k: None)
+    sys.modules["sgfsave"] = sgfsave
+    model = types.ModuleType("model")
+    model.load_best_model = lambda *a, **k: None
+    model.load_latest_model = lambda *a, **k: None
+    sys.modules["model"] = model
+    from conf import conf
+    conf["SIZE"] = size
+    conf["KOMI"] = komi
+    conf["MCTS_SIMULATIONS"] = sims
+    conf["ENERGY"] = energy
+    conf["N_GAME_PROCESS"] = 1
+    conf["SHOW_EACH_MOVE"] = False
+    conf["SHOW_END_GAME"] = False
+    return conf
+
+
+def _sha8(arr):
+    import numpy as np
+    return np.frombuffer(hashlib.sha1(np.ascontiguousarray(arr).tobytes()).digest()[:8], dtype=np.uint8)
+
+
+def _board_i8(board):
+    import numpy as np
+    return board[0].astype(np.int8)
+
+
+SCRIPTED_9 = {
+    # name: list of (x, y, color) ; color 0 = None (to-play).  y == 9 is a pass.
+    # Situations mirror the ones the reference pins in test/tests.py:215-481 (self-suicide,
+    # capture-is-not-suicide, suicide, ko, two-stone capture is not ko, corner captures).
+    "self_suicide": [(0, 0, 0), (1, 0, 0), (8, 9, 0), (2, 1, 0), (8, 8, 0), (3, 0, 0), (2, 0, 0)],
+    "capture_not_suicide": [(0, 0, 0), (1, 0, 0), (1, 1, 0), (2, 1, 0), (8, 8, 0), (3, 0, 0), (2, 0, 0)],
+    "suicide_illegal": [(0, 1, 0), (1, 0, 0), (1, 1, 0), (2, 1, 0), (8, 8, 0), (3, 0, 0)],
+    "ko": [(1, 0, 0), (2, 0, 0), (0, 1, 0), (3, 1, 0), (1, 2, 0), (2, 2, 0), (2, 1, 0), (1, 1, 0),
+           (8, 8, 0), (7, 7, 0), (2, 1, 0)],
+    "two_stone_capture": [(2, 0, 0), (0, 0, 0), (2, 1, 0), (1, 0, 0), (0, 2, 0), (0, 1, 0), (1, 2, 0),
+                          (1, 1, 0), (8, 8, 0), (8, 9, 0), (7, 7, 0), (8, 9, 0), (2, 2, 0), (8, 9, 0)],
+    "explicit_colors": [(2, 1, 1), (2, 0, 1), (3, 1, -1), (1, 1, 1), (4, 1, -1), (2, 2, -1), (3, 0, -1),
+                        (3, 2, 1), (8, 9, -1), (8, 9, 1), (0, 0, 1), (0, 1, -1), (1, 0, -1)],
+    "corner_eye": [(1, 0, 0), (8, 8, 0), (0, 1, 0), (8, 7, 0), (1, 1, 0), (0, 0, 0), (7, 8, 0), (0, 0, 0)],
+    "double_pass": [(4, 4, 0), (8, 9, 0), (8, 9, 0), (3, 3, 0)],
+}
+
+
+def child_rules(size, out):
+    """Random + scripted playouts through make_play / legal_moves / get_winner."""
+    import numpy as np
+    _setup_reference(size, 8, 8)
+    import play
+    S, A = size, size * size + 1
+    rng = np.random.RandomState(1234 + size)
+    data = {}
+    games = []
+    if size == 9:
+        for name in sorted(SCRIPTED_9):
+            games.append(("scripted_" + name, SCRIPTED_9[name]))
+    n_random = {5: 6, 7: 4, 9: 8, 13: 3, 19: 5}[size]
+    for g in range(n_random):
+        games.append(("random_%d" % g, None))
+    for gi, (name, script) in enumerate(games):
+        board, _ = play.game_init()
+        moves, players, masks, hashes, fulls, full_at, winners = [], [], [], [], [], [], []
+        masks.append(np.packbits(play.legal_moves(board).astype(np.uint8)))
+        hashes.append(_sha8(board))
+        max_plies = len(script) if script is not None else int(rng.randint(S * S // 2, 2 * S * S))
+        use_colors = script is None and (gi % 4 == 3)
+        for ply in range(max_plies):
+            if script is not None:
+                x, y, color = script[ply]
+            else:
+                mask = play.legal_moves(board)
+                r = rng.rand()
+                empties = [i for i in range(S * S)
+                           if board[0, i // S, i % S, 0] == 0 and board[0, i // S, i % S, 1] == 0]
+                legal = [i for i in range(S * S) if mask[i] == 0]
+                if r < 0.04 or not empties:
+                    a = S * S
+                elif r < 0.16 or not legal:
+                    a = empties[rng.randint(len(empties))]  # may be a suicide / ko-violating move
+                else:
+                    a = legal[rng.randint(len(legal))]
+                x, y = play.index2coord(a)
+                color = 0
+                if use_colors and rng.rand() < 0.3:
+                    color = int(rng.choice([-1, 1]))
+            b2, mover = play.make_play(x, y, board, None if color == 0 else color)
+            assert b2 is board
+            moves.append((x, y, color))
+            players.append(int(mover))
+            masks.append(np.packbits(play.legal_moves(board).astype(np.uint8)))
+            hashes.append(_sha8(board))
+            if ply % 16 == 15 or ply == max_plies - 1:
+                fulls.append(_board_i8(board))
+                full_at.append(ply + 1)
+                w, bp, wp = play.get_winner(board)
+                winners.append((int(w), int(bp), float(wp)))
+        p = "g%02d_" % gi
+        data[p + "moves"] = np.array(moves, dtype=np.int16).reshape(-1, 3)
+        data[p + "players"] = np.array(players, dtype=np.int8)
+        data[p + "masks"] = np.array(masks, dtype=np.uint8)
+        data[p + "hashes"] = np.array(hashes, dtype=np.uint8)
+        data[p + "fulls"] = np.array(fulls, dtype=np.int8).reshape(-1, S, S, 17)
+        data[p + "full_at"] = np.array(full_at, dtype=np.int32)
+        data[p + "winners"] = np.array(winners, dtype=np.float64).reshape(-1, 3)
+        data[p + "name"] = np.frombuffer(name.encode(), dtype=np.uint8)
+    data["n_games"] = np.array(len(games), dtype=np.int32)
+    data["size"] = np.array(size, dtype=np.int32)
+    data["komi"] = np.array(5.5)
+    np.savez_compressed(out, **data)
+
+
+def child_sgf(out):
+    """Replays of the reference's own 19x19 fixtures real_games/*.sgf (moves become data)."""
+    import numpy as np
+    size = 19
+    _setup_reference(size, 8, 8)
+    import play
+    data = {}
+    names = sorted(os.listdir(os.path.join(REF, "real_games")))
+    for gi, fn in enumerate(names):
+        txt = open(os.path.join(REF, "real_games", fn)).read()
+        seq = re.findall(r";([BW])\[([a-s]{0,2})\]", txt)
+        board, _ = play.game_init()
+        moves, masks, hashes, fulls, full_at, winners = [], [], [], [], [], []
+        masks.append(np.packbits(play.legal_moves(board).astype(np.uint8)))
+        hashes.append(_sha8(board))
+        for ply, (c, co) in enumerate(seq):
+            if co == "":
+                x, y = 0, size
+            else:
+                x, y = ord(co[0]) - 97, ord(co[1]) - 97
+            color = 1 if c == "B" else -1
+            play.make_play(x, y, board, color)
+            moves.append((x, y, color))
+            masks.append(np.packbits(play.legal_moves(board).astype(np.uint8)))
+            hashes.append(_sha8(board))
+            if ply % 16 == 15 or ply == len(seq) - 1:
+                fulls.append(_board_i8(board))
+                full_at.append(ply + 1)
+                w, bp, wp = play.get_winner(board)
+                winners.append((int(w), int(bp), float(wp)))
+        p = "g%02d_" % gi
+        data[p + "moves"] = np.array(moves, dtype=np.int16)
+        data[p + "masks"] = np.array(masks, dtype=np.uint8)
+        data[p + "hashes"] = np.array(hashes, dtype=np.uint8)
+        data[p + "fulls"] = np.array(fulls, dtype=np.int8)
+        data[p + "full_at"] = np.array(full_at, dtype=np.int32)
+        data[p + "winners"] = np.array(winners, dtype=np.float64)
+        data[p + "name"] = np.frombuffer(fn.encode(), dtype=np.uint8)
+        data[p + "final_sha1"] = np.frombuffer(hashlib.sha1(board.tobytes()).hexdigest()[:12].encode(), dtype=np.uint8)
+    data["n_games"] = np.array(len(names), dtype=np.int32)
+    data["size"] = np.array(size, dtype=np.int32)
+    data["komi"] = np.array(5.5)
+    np.savez_compressed(out, **data)
+
+
+def child_sym(size, out):
+    import numpy as np
+    _setup_reference(size, 8, 8)
+    import symmetry as sy
+    S, A = size, size * size + 1
+    # canonical order used by this repo: 0 id, 1 left_diagonal, 2 vertical_axis, 3 horizontal_axis,
+    # 4 rot90, 5 rot180, 6 rot270 (= symmetry.SYMMETRIES order, symmetry.py:117-125), 7 right_diagonal.
+    fwd = [sy._id, sy.left_diagonal, sy.vertical_axis, sy.horizontal_axis, sy.rotation_90,
+           sy.rotation_180, sy.rotation_270, sy.right_diagonal]
+    rev = [sy._id, sy.reverse_left_diagonal, sy.reverse_vertical_axis, sy.reverse_horizontal_axis,
+           sy.reverse_rotation_90, sy.reverse_rotation_180, sy.reverse_rotation_270,
+           sy.reverse_right_diagonal]
+    luts = [list(range(A)), sy.LEFT_DIAGONAL_SWAP, sy.VERTICAL_AXIS_SWAP, sy.HORIZONTAL_AXIS_SWAP,
+            sy.ROTATION_90_SWAP, sy.ROTATION_180_SWAP, sy.ROTATION_270_SWAP, sy.RIGHT_DIAGONAL_SWAP]
+    assert [f for f, _ in sy.SYMMETRIES] == fwd[:7]
+    rng = np.random.RandomState(77 + size)
+    boards = rng.randint(-1, 2, size=(3, S, S, 17)).astype(np.int32)
+    policy = rng.rand(3, A).astype(np.float32)
+    data = {"size": np.array(size, dtype=np.int32), "boards": boards.astype(np.int8), "policy": policy,
+            "luts": np.array(luts, dtype=np.int32)}
+    for k in range(8):
+        tb = np.array(fwd[k](np.copy(boards)))
+        data["fwd%d" % k] = tb.astype(np.int8)
+        data["rev%d" % k] = np.array(rev[k](np.copy(policy)))
+        # round trip the reference relies on: a net that is equivariant sees policy transformed like the board
+    np.savez_compressed(out, **data)
+
+
+def child_puct(out):
+    """Unit-level selectors: top_one_with_virtual_loss / top_one_action / top_n_actions on random
+    child tables, in the two dtype regimes the reference produces under numpy 2 (float32 priors from
+    the net; float64 priors after Dirichlet mixing at a fresh root)."""
+    import numpy as np
+    _setup_reference(9, 8, 8)
+    import play
+    rng = np.random.RandomState(4242)
+    A = 82
+    n_cases = 600
+    P = np.zeros((n_cases, A), dtype=np.float64)
+    N = np.zeros((n_cases, A), dtype=np.int32)
+    Q = np.zeros((n_cases, A), dtype=np.float32)
+    V = np.zeros((n_cases, A), dtype=np.int8)
+    EX = np.zeros((n_cases, A), dtype=np.int8)
+    F64 = np.zeros((n_cases,), dtype=np.int8)
+    out_vl = np.zeros((n_cases,), dtype=np.int32)
+    out_one = np.zeros((n_cases,), dtype=np.int32)
+    out_top = np.full((n_cases, 8), -1, dtype=np.int32)
+    for c in range(n_cases):
+        f64 = c % 3 == 2
+        F64[c] = f64
+        exist = rng.rand(A) < rng.choice([0.05, 0.3, 0.9, 1.0])
+        if not exist.any():
+            exist[rng.randint(A)] = True
+        levels = rng.choice([3, 10, 1000])
+        hi = int(rng.choice([1, 4, 60, 2000]))
+        subtree = {}
+        for a in range(A):
+            if not exist[a]:
+                continue
+            if f64:
+                p = np.float64(rng.randint(1, levels + 1)) / np.float64(levels * 7)
+            else:
+                p = np.float32(rng.randint(1, levels + 1)) / np.float32(levels * 7)
+            n = int(rng.randint(0, hi)) if rng.rand() < 0.6 else 0
+            if n:
+                value = np.float32(0)
+                for _ in range(min(n, 5)):
+                    value = value + np.float32(rng.uniform(-1, 1))
+                q = value / float(n)
+                assert type(q) is np.float32
+            else:
+                q = 0
+            vl = 2 if rng.rand() < rng.choice([0.0, 0.2, 0.97]) else 0
+            subtree[a] = {"index": a, "count": n, "value": 0, "mean_value": q, "p": p, "subtree": {},
+                          "parent": None, "virtual_loss": vl}
+            P[c, a], N[c, a], Q[c, a], V[c, a], EX[c, a] = p, n, q, vl, 1
+        r = play.top_one_with_virtual_loss({"subtree": subtree})
+        out_vl[c] = r["action"] if r else -1
+        r = play.top_one_action(subtree)
+        out_one[c] = r["action"]
+        r = play.top_n_actions(subtree, 8)
+        for i, d in enumerate(r):
+            out_top[c, i] = d["action"]
+    np.savez_compressed(out, P=P, N=N, Q=Q, V=V, EX=EX, F64=F64, out_vl=out_vl, out_one=out_one, out_top=out_top)
+
+
+def _tree_hash(root):
+    """Canonical serialisation: pre-order, ascending action; per child
+    <i action, i count, f value, f mean_value, d p, i virtual_loss, i expanded>."""
+    import numpy as np
+    h = hashlib.sha1()
+    n_nodes = 0
+    n_expanded = 0
+    stack = [root]
+    # explicit pre-order with ascending children
+    def rec(node):
+        nonlocal n_nodes, n_expanded
+        for a in node["subtree"]:
+            c = node["subtree"][a]
+            for k in ("value", "mean_value"):
+                assert isinstance(c[k], (int, np.float32)), (k, type(c[k]))
+            assert isinstance(c["p"], (np.float32, np.float64)), type(c["p"])
+            h.update(struct.pack("<iiffdii", int(a), int(c["count"]), float(c["value"]), float(c["mean_value"]),
+                                 float(c["p"]), int(c["virtual_loss"]), 1 if c["subtree"] else 0))
+            n_nodes += 1
+            if c["subtree"]:
+                n_expanded += 1
+                rec(c)
+    prev = list(root["subtree"].keys())
+    assert prev == sorted(prev)
+    rec(root)
+    return h.digest()[:16], n_nodes, n_expanded
+
+
+def child_async(size, sims, energy, net_kind, num_moves, stop_exploration, seed, out):
+    """Full play_game_async games (nomodel_self_play.py:142) with a deterministic stub net."""
+    import copy
+    import collections
+    import numpy as np
+    conf = _setup_reference(size, sims, energy)
+    conf["STOP_EXPLORATION"] = stop_exploration
+    import play
+    import symmetry
+    import predicting_queue_worker as pq
+    import simulation_workers as sw
+    import nomodel_self_play as ns
+    from sejonggo_amd.stub_nets import make_stub
+    S, A = size, size * size + 1
+    net = make_stub(net_kind, size)
+    counters = {"predict": 0, "root": 0}
+
+    def stub_predict(indicator, board, response_now=False):
+        counters["predict"] += 1
+        if response_now:
+            counters["root"] += 1
+        p, v = net.predict_on_batch(np.asarray(board))
+        assert p.dtype == np.float32 and v.dtype == np.float32
+        return p[0], v[0][0]
+
+    for m in (pq, sw, ns):
+        m.put_predict_request = stub_predict
+        m.put_name_request = lambda ind: net.name
+
+    class FakePool(object):
+        def apply_async(self, fn, args, error_callback=None, callback=None):
+            leaf, board, moves, ind, orig, pid = args
+            fn(copy.deepcopy(leaf), np.copy(board), list(moves), ind, orig, pid)  # emulate pickling
+
+        def close(self):
+            pass
+
+        def join(self):
+            pass
+
+    class FakeQueue(object):
+        def __init__(self):
+            self.q = collections.deque()
+
+        def put(self, x):
+            self.q.append(x)
+
+        def get(self):
+            if not self.q:
+                raise RuntimeError("reference would block forever: result queue empty")
+            return self.q.popleft()
+
+    sw.process_pool = FakePool()
+    sw.simulation_result_queue[0] = FakeQueue()
+
+    draw_rng = np.random.RandomState(seed)
+    rec = {"uniforms": [], "noises": [], "none_events": 0}
+
+    def fake_choice(moves, size=1, p=None):
+        u = draw_rng.random_sample()
+        rec["uniforms"].append(u)
+        cdf = np.cumsum(np.asarray(p, dtype=np.float64))
+        cdf /= cdf[-1]
+        idx = int(np.searchsorted(cdf, u, side="right"))
+        return [moves[idx]]
+
+    def fake_dirichlet(alpha):
+        g = draw_rng.gamma(alpha[0], size=len(alpha))  # any draw is fine: it is recorded
+        noise = g / g.sum()
+        rec["noises"].append(noise.astype(np.float64))
+        return noise
+
+    np.random.choice = fake_choice
+    np.random.dirichlet = fake_dirichlet
+
+    per_move = collections.defaultdict(list)
+    orig_select = ns.select_play
+
+    def wrapped_select(board, energy_, tree, temperature, indicator, gpuid):
+        a = orig_select(board, energy_, tree, temperature, indicator, gpuid)
+        n = np.zeros(A, dtype=np.int32)
+        w = np.zeros(A, dtype=np.float32)
+        q = np.zeros(A, dtype=np.float32)
+        p = np.zeros(A, dtype=np.float64)
+        ex = np.zeros(A, dtype=np.int8)
+        for mv, d in tree["subtree"].items():
+            n[mv], w[mv], q[mv], p[mv], ex[mv] = d["count"], d["value"], d["mean_value"], d["p"], 1
+        hsh, n_nodes, n_exp = _tree_hash(tree)
+        per_move["N"].append(n); per_move["W"].append(w); per_move["Q"].append(q)
+        per_move["P"].append(p); per_move["EX"].append(ex)
+        per_move["tree_hash"].append(np.frombuffer(hsh, dtype=np.uint8))
+        per_move["n_nodes"].append(n_nodes); per_move["n_expanded"].append(n_exp)
+        per_move["root_count"].append(int(tree["count"]))
+        per_move["root_value"].append(np.float32(tree["value"]))
+        per_move["action"].append(int(a))
+        per_move["temperature"].append(int(temperature))
+        return a
+
+    ns.select_play = wrapped_select
+    import io
+    import contextlib
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        gd = ns.play_game_async("BEST_SYM", "BEST_SYM", energy, stop_exploration, process_id=0,
+                                self_play=True, num_moves=num_moves)
+    rec["none_events"] = buf.getvalue().count("No best leaf")
+    moves = gd["moves"]
+    data = {
+        "size": np.array(size, dtype=np.int32), "sims": np.array(sims, dtype=np.int32),
+        "energy": np.array(energy, dtype=np.int32), "stop_exploration": np.array(stop_exploration, dtype=np.int32),
+        "num_moves": np.array(-1 if num_moves is None else num_moves, dtype=np.int32),
+        "net": np.frombuffer(net_kind.encode(), dtype=np.uint8),
+        "komi": np.array(5.5),
+        "uniforms": np.array(rec["uniforms"], dtype=np.float64),
+        "noises": np.array(rec["noises"], dtype=np.float64).reshape(-1, A),
+        "none_events": np.array(rec["none_events"], dtype=np.int32),
+        "n_predict": np.array(counters["predict"], dtype=np.int32),
+        "n_root_predict": np.array(counters["root"], dtype=np.int32),
+        "move_index": np.array([mv["move"][0] + S * mv["move"][1] if mv["move"][1] != S else S * S for mv in moves], dtype=np.int32),
+        "move_xy": np.array([mv["move"] for mv in moves], dtype=np.int32).reshape(-1, 2),
+        "move_player": np.array([mv["player"] for mv in moves], dtype=np.int8),
+        "move_value": np.array([mv["value"] for mv in moves], dtype=np.float32),
+        "move_policy": np.array([mv["policy"] for mv in moves], dtype=np.float64).reshape(-1, A),
+        "move_board_hash": np.array([_sha8(mv["board"]) for mv in moves], dtype=np.uint8).reshape(-1, 8),
+        "first_board": _board_i8(moves[0]["board"]) if moves else np.zeros((S, S, 17), np.int8),
+        "last_board": _board_i8(moves[-1]["board"]) if moves else np.zeros((S, S, 17), np.int8),
+        "winner": np.array(-99 if gd["winner"] is None else gd["winner"], dtype=np.int32),
+        "result": np.frombuffer(gd["result"].encode(), dtype=np.uint8),
+    }
+    for k, v in per_move.items():
+        data["pm_" + k] = np.array(v)
+    np.savez_compressed(out, **data)
+    print("async S=%d sims=%d E=%d net=%s: %d moves, result %s, %d predicts, none_events=%d" % (
+        size, sims, energy, net_kind, len(moves), gd["result"], counters["predict"], rec["none_events"]))
+
+
+# ----------------------------------------------------------------------------------------------
+# parent side
+# ----------------------------------------------------------------------------------------------
+ASYNC_CASES = [
+    # (size, sims, energy, net, num_moves, stop_exploration, seed)
+    (9, 50, 8, "uniform", None, 30, 1),      # BASELINE.json configs[0]: 9x9, 50 sims (48 effective), stub net
+    (9, 50, 8, "dummy", None, 6, 2),
+    (9, 50, 8, "hash", None, 10, 3),
+    (9, 200, 8, "hash", 12, 4, 4),
+    (5, 48, 8, "hash", None, 4, 5),          # tiny board: few legal moves -> exercises the "no best leaf" path
+    (5, 64, 16, "dummy", None, 2, 6),
+    (19, 40, 8, "hash", 6, 3, 7),
+    (19, 400, 8, "hash", 2, 30, 8),          # the headline search width, two plies
+]
+
+
+def run_child(args, cwd):
+    env = dict(os.environ)
+    env["PYTHONDONTWRITEBYTECODE"] = "1"
+    cmd = [sys.executable, os.path.abspath(__file__), "--child"] + [str(a) for a in args]
+    print("+", " ".join(cmd[2:]), flush=True)
+    subprocess.check_call(cmd, cwd=cwd, env=env)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--child", nargs="+")
+    ap.add_argument("--only", default=None)
+    a = ap.parse_args()
+    if a.child:
+        what = a.child[0]
+        if what == "rules":
+            child_rules(int(a.child[1]), a.child[2])
+        elif what == "sgf":
+            child_sgf(a.child[1])
+        elif what == "sym":
+            child_sym(int(a.child[1]), a.child[2])
+        elif what == "puct":
+            child_puct(a.child[1])
+        elif what == "async":
+            s, sims, e, net, nm, se, seed, out = a.child[1:]
+            child_async(int(s), int(sims), int(e), net, None if nm == "None" else int(nm), int(se), int(seed), out)
+        return
+    scratch = tempfile.mkdtemp(prefix="sgo_golden_")
+    only = a.only
+    if only in (None, "rules"):
+        for s in (5, 7, 9, 13, 19):
+            run_child(["rules", s, os.path.join(HERE, "rules_S%d.npz" % s)], scratch)
+    if only in (None, "sgf"):
+        run_child(["sgf", os.path.join(HERE, "sgf_S19.npz")], scratch)
+    if only in (None, "sym"):
+        for s in (5, 9, 19):
+            run_child(["sym", s, os.path.join(HERE, "sym_S%d.npz" % s)], scratch)
+    if only in (None, "puct"):
+        run_child(["puct", os.path.join(HERE, "puct.npz")], scratch)
+    if only in (None, "async"):
+        for i, c in enumerate(ASYNC_CASES):
+            run_child(["async"] + list(c) + [os.path.join(HERE, "async_%02d.npz" % i)], scratch)
+
+
+if __name__ == "__main__":
+    main()
