@@ -1,0 +1,178 @@
+/*
+ * sgo.h -- C ABI of libsgo_hip.so, the MI355X (gfx950) self-play hot path of sejonggo.
+ *
+ * The reference (drsagitn/sejonggo) is pure Python and has no FFI; its boundary for this path is a
+ * set of Python module symbols.  This header is the C ABI placed underneath those
+ * symbols: plain pointers and sizes, no torch types, `int` return 0 = ok / negative = error (text via
+ * sgo_last_error()).  Each entry point cites the reference interface it replaces (file:line relative
+ * to the reference repo).  INTEGRATION.md shows the ctypes binding a maintainer adds on the
+ * reference side.
+ *
+ * Conventions
+ *   board17   int32 [n][S][S][17]  the reference's board tensor (play.py:295-299), NHWC, plane 2k =
+ *             to-play side's stones k plies ago, 2k+1 = opponent's, plane 16 = to-play colour (+1/-1).
+ *   action    a = y*S + x, pass = S*S                                   (play.py:31-37)
+ *   packed    uint32 [n][sgo_packed_words(S)]  16 bit-planes of ceil(S*S/32) words (bit a of plane c
+ *             = board17[...a..., c] != 0) + 1 meta word (bit0: to-play is white), padded to 16 B.
+ *   legal     uint32 [n][sgo_plane_words(S)]   bit a = 1 <=> action a is LEGAL (pass bit always 1).
+ *   *_dev     arguments are DEVICE pointers; `stream` is a hipStream_t passed as void*.
+ *   host entry points (no _dev suffix) copy caller HOST buffers to the GPU, run the same kernels and
+ *   copy back; they exist for drop-in use and parity tests, not for throughput.
+ *   Supported board sizes: 5, 7, 9, 13, 19.
+ *
+ * There is no CPU fallback anywhere in this library: without a HIP device every call fails.
+ */
+#ifndef SGO_H
+#define SGO_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGO_OK 0
+#define SGO_ERR_ARG (-1)          /* bad size / null pointer / unsupported board size */
+#define SGO_ERR_HIP (-2)          /* HIP runtime error, see sgo_last_error() */
+#define SGO_ERR_OCCUPIED (-101)   /* play.py:233-234 assert: stone on an occupied point */
+#define SGO_ERR_RANGE (-102)      /* coordinates outside the board (IndexError in the reference) */
+#define SGO_ERR_CAPACITY (-201)   /* a game's tree-block pool is exhausted */
+#define SGO_ERR_DRAWS (-202)      /* ran out of injected random draws */
+#define SGO_ERR_STATE (-203)      /* call sequence violated */
+
+const char *sgo_last_error(void);
+int sgo_version(void);
+int sgo_device_count(void);
+int sgo_set_device(int device_id);
+
+/* ---- geometry ---------------------------------------------------------------------------------- */
+int sgo_plane_words(int S);   /* ceil(S*S/32); also the number of words of a legal bitset */
+int sgo_packed_words(int S);  /* words per packed position record */
+int sgo_apad(int S);          /* child slots per tree block (= 32 * plane_words) */
+
+/* ---- stateless rules on HOST buffers (drop-in for play.py) -------------------------------------- */
+/* play.py:295-299 game_init */
+int sgo_game_init(int S, int n, int32_t *board17);
+/* play.py:226-242 make_play (+ :182-217 take_stones, :159-180 capture_group, :219-224 swap_player).
+ * colors[i] = 0 means "color=None".  movers[i] receives the player who moved; status[i] is SGO_OK or
+ * SGO_ERR_OCCUPIED / SGO_ERR_RANGE (board i is then left untouched).  Returns SGO_OK if the batch ran. */
+int sgo_make_play(int S, int n, int32_t *board17, const int32_t *xs, const int32_t *ys, const int32_t *colors,
+                  int32_t *movers, int32_t *status);
+/* play.py:71-104 legal_moves: mask[n][S*S+1], 1 = ILLEGAL (the reference's convention), pass = 0 */
+int sgo_legal_moves(int S, int n, const int32_t *board17, uint8_t *mask);
+/* play.py:274-292 get_winner/_get_points: winner +1/0/-1, black points, white points (incl. komi) */
+int sgo_get_winner(int S, int n, const int32_t *board17, double komi, int32_t *winner, int32_t *black, double *white);
+/* symmetry.py:45-114 board transforms; k: 0 id, 1 left_diagonal, 2 vertical_axis, 3 horizontal_axis,
+ * 4 rotation_90, 5 rotation_180, 6 rotation_270 (order of symmetry.SYMMETRIES, :117-125), 7 right_diagonal */
+int sgo_sym_apply(int S, int k, int n, const int32_t *in17, int32_t *out17);
+/* symmetry.py reverse_*: out[i][a] = in[i][SWAP_k[a]] */
+int sgo_sym_invert_policy(int S, int k, int n, const float *in, float *out);
+/* symmetry.py:12-42 the SWAP table itself (A entries) */
+int sgo_sym_lut(int S, int k, int32_t *lut);
+
+/* ---- device-resident batch kernels (the data-parallel hot path) --------------------------------- */
+int sgo_pack_dev(int S, int n, const int32_t *d_board17, uint32_t *d_packed, void *stream);
+int sgo_unpack_dev(int S, int n, const uint32_t *d_packed, int32_t *d_board17, void *stream);
+/* board_advance: for i<n  out[out_idx?out_idx[i]:i] = make_play(in[in_idx?in_idx[i]:i], moves[i]) and
+ * legal[...] = legal bits of the new position.  moves[i] = action index; colors may be NULL (None);
+ * status may be NULL.  in and out may alias record-for-record (in place). */
+int sgo_advance_legal_dev(int S, int n, const uint32_t *d_in, const int32_t *d_in_idx, const int32_t *d_moves,
+                          const int32_t *d_colors, uint32_t *d_out, const int32_t *d_out_idx, uint32_t *d_legal,
+                          int32_t *d_status, void *stream);
+int sgo_legal_dev(int S, int n, const uint32_t *d_packed, const int32_t *d_idx, uint32_t *d_legal, void *stream);
+/* d_result[i] = {winner, black, white_stones_and_territory (without komi)} as 3 x int32 */
+int sgo_score_dev(int S, int n, const uint32_t *d_packed, const int32_t *d_idx, double komi, int32_t *d_result,
+                  void *stream);
+/* nn_input_pack (+ fused sym_apply): network input for positions d_packed[d_idx[i]], transformed by
+ * symmetry k.  layout 0: NHWC [n][S][S][17], 1: NCHW [n][17][S][S]; dtype 0: fp16, 1: fp32. */
+int sgo_nn_pack_dev(int S, int n, const uint32_t *d_packed, const int32_t *d_idx, int k, int layout, int dtype,
+                    void *d_out, void *stream);
+
+/* ---- self-play engine: virtual-loss PUCT + game loop, many games resident on one GPU ------------ */
+/* Replaces nomodel_self_play.py:59-82 async_simulate2, :114-140 select_play, :142-271 play_game_async,
+ * tree_util.py:4-32, play.py:308-323/376-421, simulation_workers.py:42-54 basic_tasks2 and the request
+ * side of predicting_queue_worker.py:40-102.  One ctx per GPU; not thread-safe. */
+typedef struct sgo_ctx sgo_ctx;
+
+typedef struct sgo_config {
+    int32_t size;             /* conf['SIZE'] */
+    int32_t n_games;          /* concurrent game slots */
+    int32_t sims;             /* conf['MCTS_SIMULATIONS'] */
+    int32_t energy;           /* conf['ENERGY'] (<= 64) */
+    int32_t stop_exploration; /* conf['STOP_EXPLORATION'] */
+    int32_t num_moves;        /* play_game_async(num_moves); <0 => 2*S*S */
+    int32_t blocks_per_game;  /* tree-block pool per game; <=0 => 3*sims + 64 */
+    int32_t self_play;        /* add Dirichlet noise when a tree is created (play.py:400-403) */
+    double komi;              /* conf['KOMI'] */
+    double dirichlet_epsilon; /* conf['DIRICHLET_EPSILON'] */
+    int32_t device_id;
+    int32_t reserved;
+} sgo_config;
+
+typedef struct sgo_status {
+    int32_t n_eval;       /* positions waiting for a network evaluation after this step */
+    int32_t n_records;    /* move records waiting in the record buffer */
+    int32_t n_active;     /* game slots still playing */
+    int32_t n_done;       /* game slots finished and not yet restarted */
+    int32_t error;        /* first error raised by any game (SGO_ERR_*) or 0 */
+    int32_t error_game;
+    int64_t total_moves;  /* moves played since ctx creation */
+    int64_t total_evals;  /* network evaluations consumed since ctx creation */
+    int64_t none_events;  /* "No best leaf" events (nomodel_self_play.py:70-75) */
+} sgo_status;
+
+/* one record per move played = the reference's move_data (nomodel_self_play.py:187-194) */
+typedef struct sgo_move_record {
+    int32_t game;      /* slot */
+    int32_t game_seq;  /* how many games this slot had finished before this one */
+    int32_t move_n;
+    int32_t action;
+    int32_t player;    /* 'player' exactly as the reference records it */
+    float value;       /* raw network value at the root */
+} sgo_move_record;
+
+typedef struct sgo_game_result {
+    int32_t winner;      /* +1 black, -1 white, 0 draw (play.py:274-284) */
+    int32_t black;       /* black points */
+    double white;        /* white points incl. komi */
+    int32_t end_reason;  /* 0 PLAYED ALL MOVES, 1 resign, 2 BOTH_PASSED */
+    int32_t n_moves;
+    int32_t last_player; /* 'player' when the loop ended (used for "X+R") */
+    int32_t done;
+} sgo_game_result;
+
+sgo_ctx *sgo_ctx_create(const sgo_config *cfg);
+void sgo_ctx_destroy(sgo_ctx *ctx);
+/* (Re)start game slots.  noise: [n][A] float64 Dirichlet draws (np.random.dirichlet stand-in, consumed
+ * when a tree is created); uniforms: [n][n_uniforms] float64 in [0,1) consumed one per sampled move
+ * (np.random.choice stand-in); resign: [n] thresholds, NaN = None.  HOST pointers. */
+int sgo_start_games(sgo_ctx *ctx, int n, const int32_t *slots, const double *noise, const double *uniforms,
+                    int n_uniforms, const float *resign);
+/* One engine step.  Consumes the evaluations of the positions listed by the previous step
+ * (d_policy [n_eval][A] float32, d_value [n_eval] float32, produced from inputs transformed by
+ * symmetry sym_k; NULL on the first call), back-propagates, selects the next leaves, plays moves whose
+ * search is complete, computes the new leaf positions, and reports what must be evaluated next.
+ * Synchronises `stream` once to return `st`. */
+int sgo_step(sgo_ctx *ctx, const float *d_policy, const float *d_value, int sym_k, void *stream, sgo_status *st);
+/* Network input for the positions listed by the last sgo_step (same order as the results expected). */
+int sgo_collect(sgo_ctx *ctx, int sym_k, int layout, int dtype, void *d_nn_in, void *stream);
+/* Move records produced so far (HOST buffers): recs[cap], boards packed [cap][packed_words],
+ * policy targets [cap][A] float64.  Returns the number written (>=0) and clears the buffer. */
+int sgo_drain_records(sgo_ctx *ctx, int cap, sgo_move_record *recs, uint32_t *packed, double *policy);
+int sgo_game_results(sgo_ctx *ctx, int n, const int32_t *slots, sgo_game_result *out);
+/* Introspection for parity tests: root child table of a slot's current tree and the canonical
+ * serialisation of the whole tree (32-byte records, see oracle/sgo_oracle.c ora_game_tree_serialize). */
+int sgo_root_table(sgo_ctx *ctx, int slot, int32_t *N, float *W, float *Q, double *P, int8_t *EX, int32_t *root_count,
+                   float *root_value);
+int64_t sgo_tree_serialize(sgo_ctx *ctx, int slot, uint8_t *buf, int64_t cap, int64_t *n_nodes, int64_t *n_expanded);
+int sgo_game_board(sgo_ctx *ctx, int slot, int32_t *board17);
+/* test hook: stop slot right before the move choice of move_n == k (phase becomes done, error 0) */
+int sgo_set_halt(sgo_ctx *ctx, int slot, int move_n);
+/* average duration (ms) and launch count of the board_advance kernel inside sgo_step since the last
+ * call (HIP events on the step's stream); used by bench.py for the roofline object */
+int sgo_advance_timing(sgo_ctx *ctx, double *total_ms, int64_t *launches, int64_t *positions);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

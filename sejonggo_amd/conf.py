@@ -1,0 +1,32 @@
+"""Hot-path configuration keys, same names and defaults as the reference's conf.py:3-106 (only the
+keys the self-play path reads; hosts/credentials of the reference's cluster config are not part of it)."""
+conf = {
+    'MODEL_DIR': 'sp_models',
+    'SELF_PLAY_DIR': 'sp_self_play_data',
+    'BEST_MODEL': 'best_model.h5',
+    'SHOW_EACH_MOVE': False,
+    'SHOW_END_GAME': False,
+    'GPUs': [0, 1, 2, 3, 4, 5, 6, 7],
+    'PREDICTING_BATCH_SIZE': 32,
+    'N_RESIDUAL_BLOCKS': 20,
+    'N_GAMES': 5000,
+    'GAME_RANGE': [0, 5000],
+    'MCTS_SIMULATIONS': 1600,
+    'N_GAME_PROCESS': 32,
+    'ENERGY': 8,
+    'SIZE': 19,
+    'KOMI': 5.5,
+    'STOP_EXPLORATION': 30,
+    'MCTS_BATCH_SIZE': 100,
+    'DIRICHLET_ALPHA': .03,
+    'DIRICHLET_EPSILON': .25,
+    'RESIGNATION_PERCENT': .10,
+    'RESIGNATION_ALLOWED_ERROR': .05,
+    'TRAINING_SERVER': None,
+    'SGF_ENABLED': False,
+    # build-side knobs (not in the reference)
+    'GAMES_PER_GPU': 1024,       # concurrent game slots resident on one MI355X
+    'NET_DTYPE': 'fp16',
+    'SYMMETRY_MODE': 'random1',  # 'random1' = reference behaviour (symmetry.py:127-132); 'avg8' = 8-fold averaging
+    'COMPAT_Z': True,            # reproduce sgfsave.py:56 value_target quirk
+}

@@ -1,0 +1,1071 @@
+// sgo_engine.hip -- device-resident self-play engine: virtual-loss PUCT search + game loop for many
+// concurrent games on one MI355X.  Second half of the C ABI in include/sgo.h.
+//
+// What it replaces (reference = drsagitn/sejonggo, file:line):
+//   play.py:308-323 top_one_with_virtual_loss, tree_util.py:4-24 find_best_leaf_virtual_loss,
+//   play.py:376-421 new_tree/new_subtree, simulation_workers.py:42-54 basic_tasks2,
+//   nomodel_self_play.py:40-56 back_propagation, :59-82 async_simulate2, :114-140 select_play,
+//   :142-271 play_game_async, and the request side of predicting_queue_worker.py:40-102.
+//
+// Execution model
+//   * ONE WAVEFRONT PER GAME runs the game's state machine (k_search): the descent does a 64-lane
+//     argmax over the <=362 child slots of a node (6 slots per lane at 19x19, butterfly reduce), busy
+//     flags and back-off exactly as the reference; expansion and garbage collection use wave ballots +
+//     prefix popcounts.  Games never talk to each other, so there is no inter-workgroup hand-off.
+//   * Per engine step: k_search (consume evaluations -> back-propagate -> select next leaves / play a
+//     move) -> k_compact (prefix sums over games: dense evaluation list + leaf list) -> board_advance
+//     (k_advance_legal, one LANE per leaf) -> [host runs the network on the packed inputs] -> next step.
+//   * Tree storage: every game owns `cap` fixed-size BLOCKS.  A block = one expanded node: its packed
+//     position, legal bitset, and APAD child slots in struct-of-arrays form (P, N, W, Q, child block,
+//     busy) so that the lanes of the selecting wave read consecutive slots (coalesced).  Child slot i
+//     is only ever touched by lane (i & 63) of the game's wave.  Blocks are recycled by a
+//     mark-and-rebuild pass when the tree is re-rooted after a move.
+//
+// Float regime (must match oracle/sgo_oracle.c, i.e. the reference under numpy>=2): W/Q/score in
+// float32; at a root whose priors were mixed with Dirichlet noise priors and score are float64.
+#include <math.h>
+#include <string.h>
+#include <vector>
+
+#include "sgo_bits.hpp"
+#include "sgo_common.hpp"
+
+namespace sgo {
+
+enum { PH_IDLE = 0, PH_WAIT_ROOT = 1, PH_SEARCH = 2, PH_DONE = 3 };
+#define MAXE 64
+
+struct GameState {
+    int32_t phase, root_blk, move_n, player;
+    int32_t temperature, skipped_last, has_value, end_reason;
+    float value, last_value, resign;
+    int32_t has_resign;
+    int32_t error, rounds_left, e_left, pre_bp;
+    int32_t need_bp, original_player, fifo_head, fifo_tail;
+    int32_t free_top, root_f64, root_count, halt_at;
+    float root_value, root_mean;
+    int32_t i_uniform, n_uniform;
+    int32_t noise_used, game_seq, n_req, req_kind;
+    int32_t eval_base, root_requested, winner, black;
+    double white;
+    int32_t n_moves, last_player;
+    int64_t n_predict, none_events;
+};
+
+struct Counters {
+    int32_t rec_count;
+    int32_t pad;
+    unsigned long long total_moves, total_evals, none_events;
+};
+
+struct DevStatus {  // written by k_compact, copied to the host once per step
+    int32_t n_eval, n_leaf, n_records, n_active, n_done, error, error_game, pad;
+    unsigned long long total_moves, total_evals, none_events;
+};
+
+struct Ctx {
+    sgo_config cfg;
+    int S, A, APAD, NW, RW, G, E, cap;
+    int max_moves;       // effective num_moves
+    int rec_cap;
+    // device arrays
+    GameState *gs;
+    uint32_t *pos;        // [G*cap][RW]
+    uint32_t *legal;      // [G*cap][NW]
+    float *cP, *cW, *cQ;  // [G*cap][APAD]
+    int32_t *cN, *cB;     // counts, child block (local index, -1 = not expanded)
+    uint8_t *cBusy;
+    int32_t *bParent;     // [G*cap] local parent block (-1 root)
+    int32_t *bSlot;       // [G*cap] slot in parent
+    int32_t *freeList;    // [G][cap]
+    double *rootP64;      // [G][APAD]
+    double *noise;        // [G][APAD]
+    double *uniforms;     // [G][max_moves]
+    // fifo
+    int32_t *fParent, *fSlot, *fBlk, *fEvalLocal, *fEvaluated;  // [G][2E]
+    float *fValue;
+    // requests of the current step
+    int32_t *reqBlk, *reqParent, *reqMove;  // [G][E]; block ids are GLOBAL (g*cap + local)
+    // compacted lists
+    int32_t *evalIdx, *leafIn, *leafMv, *leafOut;  // [G*E]
+    // records
+    sgo_move_record *recs;
+    uint32_t *recPacked;
+    double *recPolicy;
+    Counters *counters;
+    DevStatus *dstatus;
+    DevStatus *hstatus;   // pinned host
+    int32_t *symLut;      // [8][A]
+    int32_t *slotList;    // [G] scratch for start_games
+    int last_n_eval;      // positions listed by the previous step
+};
+
+struct HostSide {  // not passed to kernels
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;   // bracket board_advance inside sgo_step
+    double adv_ms = 0;
+    long long adv_launches = 0, adv_positions = 0;
+};
+
+// ---------------------------------------------------------------------------------------- device helpers
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// argmax over the wave with "higher score, then lower index"; idx < 0 = no candidate
+template <typename F>
+__device__ __forceinline__ void wave_argmax(F &score, int &idx) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        F os = __shfl_xor(score, o);
+        int oi = __shfl_xor(idx, o);
+        bool take = (oi >= 0) && (idx < 0 || os > score || (os == score && oi < idx));
+        if (take) { score = os; idx = oi; }
+    }
+}
+
+template <int S>
+struct Eng {
+    using G = Geo<S>;
+    const Ctx &c;
+    int g, lane;
+    size_t gb0;  // g * cap
+    __device__ Eng(const Ctx &cc, int gg) : c(cc), g(gg), lane(threadIdx.x & 63), gb0((size_t)gg * cc.cap) {}
+
+    __device__ __forceinline__ size_t slot_base(int blk) const { return (gb0 + blk) * (size_t)G::APAD; }
+    __device__ __forceinline__ bool legal_bit(int blk, int i) const {
+        return (c.legal[(gb0 + blk) * G::NW + (i >> 5)] >> (i & 31)) & 1u;
+    }
+
+    // play.py:308-323 on block `blk`; returns chosen slot or -1
+    __device__ int top_one(int blk, bool f64) const {
+        const size_t sb = slot_base(blk);
+        int n_[G::APAD / 64 + 1];
+        int sum = 0;
+        constexpr int J = (G::APAD + 63) / 64;
+        bool ex[J], busy[J];
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+            int i = lane + 64 * j;
+            bool in = i < G::APAD;
+            ex[j] = in && legal_bit(blk, in ? i : 0);
+            n_[j] = ex[j] ? c.cN[sb + i] : 0;
+            busy[j] = ex[j] ? (c.cBusy[sb + i] > 0) : true;
+            sum += n_[j];
+        }
+        sum = wave_sum_i(sum);
+        double tn = sqrt((double)sum);
+        if (tn == 0) tn = 1;
+        int best = -1;
+        if (!f64) {
+            float bs = -100.0f;
+            const float tnf = (float)tn;
+#pragma unroll
+            for (int j = 0; j < J; j++) {
+                int i = lane + 64 * j;
+                if (!busy[j]) {
+                    float u = c.cP[sb + i] * tnf;
+                    u = u / (float)(1.0 + (double)n_[j]);
+                    float v = c.cQ[sb + i] + u;
+                    if (v > bs) { bs = v; best = i; }
+                }
+            }
+            wave_argmax<float>(bs, best);
+        } else {
+            double bs = -100.0;
+            const double *p64 = c.rootP64 + (size_t)g * G::APAD;
+#pragma unroll
+            for (int j = 0; j < J; j++) {
+                int i = lane + 64 * j;
+                if (!busy[j]) {
+                    double u = p64[i] * tn / (1. + (double)n_[j]);
+                    double v = (double)c.cQ[sb + i] + u;
+                    if (v > bs) { bs = v; best = i; }
+                }
+            }
+            wave_argmax<double>(bs, best);
+        }
+        return best;
+    }
+
+    // tree_util.py:4-24.  Returns true and (pblk, slot) of the leaf (flagged busy), or false ("None").
+    __device__ bool find_best_leaf(const GameState &st, int &pblk, int &slot) const {
+        int node = st.root_blk;
+        for (;;) {
+            int a = top_one(node, st.root_f64 && node == st.root_blk);
+            if (a < 0) {
+                int par = c.bParent[gb0 + node];
+                if (par < 0) return false;
+                int ps = c.bSlot[gb0 + node];
+                if (lane == (ps & 63)) c.cBusy[slot_base(par) + ps] = 2;
+                node = par;
+                continue;
+            }
+            int cb = 0;
+            if (lane == (a & 63)) cb = c.cB[slot_base(node) + a];
+            cb = __shfl(cb, a & 63);
+            if (cb < 0) {
+                if (lane == (a & 63)) c.cBusy[slot_base(node) + a] = 2;
+                pblk = node;
+                slot = a;
+                return true;
+            }
+            node = cb;
+        }
+    }
+
+    // children of block `blk` from a policy row (play.py:391-421); legal[] of the block must be valid
+    __device__ void expand(int blk, const float *policy, const int32_t *lut, const double *noise, double eps) const {
+        const size_t sb = slot_base(blk);
+        double *p64 = c.rootP64 + (size_t)g * G::APAD;
+        for (int i = lane; i < G::APAD; i += 64) {
+            bool ex = legal_bit(blk, i);
+            float p = (ex && i < G::A) ? policy[lut[i]] : 0.0f;
+            if (noise) {
+                double t = (1.0 - eps) * (double)p;
+                double pd = ex ? t + eps * noise[i] : 0.0;
+                p64[i] = pd;
+                p = (float)pd;
+            }
+            c.cP[sb + i] = p;
+            c.cN[sb + i] = 0;
+            c.cW[sb + i] = 0.f;
+            c.cQ[sb + i] = 0.f;
+            c.cB[sb + i] = -1;
+            c.cBusy[sb + i] = 0;
+        }
+    }
+
+    // nomodel_self_play.py:40-56 + the stats part of simulation_workers.py:50-53
+    __device__ void back_propagate(GameState &st, int fi) const {
+        const size_t fo = (size_t)g * (2 * MAXE) + fi;
+        const int pb = c.fParent[fo], slot = c.fSlot[fo], nb = c.fBlk[fo];
+        const float vraw = c.fValue[fo];
+        const int leaf_player = (c.pos[(gb0 + nb) * G::RW + G::META] & 1u) ? -1 : 1;
+        const float v = (leaf_player == st.original_player) ? vraw : -vraw;
+        float leaf_value = 0.f;
+        if (lane == (slot & 63)) {
+            const size_t o = slot_base(pb) + slot;
+            int n = c.cN[o] + 1;
+            float w = c.cW[o] + v;
+            c.cN[o] = n;
+            c.cW[o] = w;
+            c.cQ[o] = w / (float)n;
+            c.cBusy[o] = 0;
+            c.cB[o] = nb;
+            leaf_value = w;
+        }
+        leaf_value = __shfl(leaf_value, slot & 63);
+        int node = pb;
+        for (;;) {
+            int par = c.bParent[gb0 + node];
+            if (par < 0) {
+                st.root_count += 1;
+                st.root_value += leaf_value;
+                st.root_mean = st.root_value / (float)st.root_count;
+                break;
+            }
+            int ps = c.bSlot[gb0 + node];
+            if (lane == (ps & 63)) {
+                const size_t o = slot_base(par) + ps;
+                int n = c.cN[o] + 1;
+                float w = c.cW[o] + leaf_value;
+                c.cN[o] = n;
+                c.cW[o] = w;
+                c.cQ[o] = w / (float)n;
+                c.cBusy[o] = 0;
+            }
+            node = par;
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------- k_search
+template <int S>
+__global__ __launch_bounds__(64) void k_search(Ctx c, const float *policy, const float *value, int sym_k) {
+    using G = Geo<S>;
+    extern __shared__ int32_t lds[];
+    int32_t *queue = lds;                       // [cap]
+    int32_t *sN = lds + c.cap;                  // [APAD]
+    float *sQ = (float *)(sN + G::APAD);        // [APAD]
+    uint32_t *marks = (uint32_t *)(sQ + G::APAD);  // [(cap+31)/32]
+    const int g = blockIdx.x;
+    const int lane = threadIdx.x;
+    Eng<S> e(c, g);
+    GameState st = c.gs[g];
+    const int32_t *lut = c.symLut + (size_t)sym_k * G::A;
+    const size_t fbase = (size_t)g * (2 * MAXE);
+    const size_t rbase = (size_t)g * c.E;
+    st.n_req = 0;
+    if (st.phase == PH_IDLE || st.phase == PH_DONE) {
+        if (lane == 0) c.gs[g].n_req = 0;
+        return;
+    }
+    bool run = true;
+
+    auto finish = [&](int reason) {
+        st.end_reason = reason;
+        int bp = 0, wp = 0;
+        if (lane == 0) score_record<S>(c.pos + (e.gb0 + st.root_blk) * G::RW, bp, wp);
+        bp = __shfl(bp, 0);
+        wp = __shfl(wp, 0);
+        double white = (double)wp + c.cfg.komi;
+        st.winner = ((double)bp > white) ? 1 : (((double)bp == white) ? 0 : -1);
+        st.black = bp;
+        st.white = white;
+        st.n_moves = st.move_n;
+        st.last_player = st.player;
+        st.phase = PH_DONE;
+        run = false;
+    };
+    auto fail = [&](int code) {
+        if (!st.error) st.error = code;
+        st.phase = PH_DONE;
+        run = false;
+    };
+
+    // ---- consume the evaluations requested by the previous step
+    if (st.phase == PH_WAIT_ROOT) {
+        if (!st.root_requested) {
+            st.root_requested = 1;
+            if (lane == 0) c.reqBlk[rbase] = (int32_t)(e.gb0 + st.root_blk);
+            st.n_req = 1;
+            st.req_kind = 0;
+            run = false;
+        } else {
+            st.root_requested = 0;
+            const float *prow = policy + (size_t)st.eval_base * G::A;
+            st.value = value[st.eval_base];
+            st.has_value = 1;
+            st.n_predict++;
+            if (lane == 0) atomicAdd(&c.counters->total_evals, 1ull);
+            if (st.has_resign && st.value <= st.resign) {
+                finish(1);
+            } else {
+                // "if not mcts_tree or not mcts_tree['subtree']": the root block carries children iff flag set
+                bool expanded = c.bSlot[e.gb0 + st.root_blk] != -2;  // -2 marks "block holds no children yet"
+                if (!expanded) {
+                    const double *noise = nullptr;
+                    if (c.cfg.self_play) {
+                        if (st.noise_used) fail(SGO_ERR_DRAWS);
+                        noise = c.noise + (size_t)g * G::APAD;
+                        st.noise_used = 1;
+                    }
+                    if (run) {
+                        e.expand(st.root_blk, prow, lut, noise, c.cfg.dirichlet_epsilon);
+                        if (lane == 0) c.bSlot[e.gb0 + st.root_blk] = -1;
+                        st.root_f64 = noise ? 1 : 0;
+                        st.root_count = 0;
+                        st.root_value = 0.f;
+                        st.root_mean = 0.f;
+                    }
+                }
+                if (run) {
+                    st.rounds_left = c.cfg.sims / c.cfg.energy;
+                    st.e_left = -1;
+                    st.original_player = (c.pos[(e.gb0 + st.root_blk) * G::RW + G::META] & 1u) ? -1 : 1;
+                    st.phase = PH_SEARCH;
+                    if (c.cfg.sims < c.cfg.energy) fail(SGO_ERR_STATE);  // zero simulations: the reference cannot pick a move
+                }
+            }
+        }
+    } else {  // PH_SEARCH: every not-yet-evaluated fifo entry was evaluated by the previous step
+        for (int fi = st.fifo_head; fi < st.fifo_tail; fi++) {
+            const size_t fo = fbase + (fi % (2 * MAXE));
+            if (c.fEvaluated[fo]) continue;
+            const int row = st.eval_base + c.fEvalLocal[fo];
+            e.expand(c.fBlk[fo], policy + (size_t)row * G::A, lut, nullptr, 0.0);
+            if (lane == 0) {
+                c.fValue[fo] = value[row];
+                c.fEvaluated[fo] = 1;
+                atomicAdd(&c.counters->total_evals, 1ull);
+            }
+            st.n_predict++;
+        }
+        __syncthreads();
+        if (st.need_bp) {
+            st.need_bp = 0;
+            e.back_propagate(st, st.fifo_head % (2 * MAXE));
+            st.fifo_head++;
+            st.pre_bp++;
+        }
+    }
+
+    // ---- async_simulate2 rounds (nomodel_self_play.py:59-82) until evaluations are needed
+    while (run && st.phase == PH_SEARCH) {
+        if (st.rounds_left == 0) {
+            // ================= select_play tail + play_game_async body (:125-138, :180-216)
+            if (st.halt_at == st.move_n) { st.phase = PH_DONE; run = false; break; }
+            const size_t sb = e.slot_base(st.root_blk);
+            for (int i = lane; i < G::APAD; i += 64) {
+                bool ex = e.legal_bit(st.root_blk, i);
+                sN[i] = ex ? c.cN[sb + i] : -1;
+                sQ[i] = ex ? c.cQ[sb + i] : 0.f;
+            }
+            __syncthreads();
+            int selected = -1;
+            int err = 0;
+            if (lane == 0) {
+                if (st.temperature == 1) {
+                    long total = 0;
+                    for (int i = 0; i < G::A; i++) if (sN[i] > 0) total += sN[i];
+                    double last = 0;
+                    for (int i = 0; i < G::A; i++) if (sN[i] > 0) last += (double)sN[i] / (double)total;  // np.cumsum
+                    if (total == 0 || st.i_uniform >= st.n_uniform) err = SGO_ERR_DRAWS;
+                    else {
+                        double u = c.uniforms[(size_t)g * c.max_moves + st.i_uniform];
+                        double acc = 0;
+                        int lastmv = -1;
+                        for (int i = 0; i < G::A; i++) {
+                            if (sN[i] <= 0) continue;
+                            acc += (double)sN[i] / (double)total;
+                            lastmv = i;
+                            if (acc / last > u) { selected = i; break; }   // searchsorted(cdf/cdf[-1], u, 'right')
+                        }
+                        if (selected < 0) selected = lastmv;
+                    }
+                } else {
+                    int bc = -1, ba = -1;
+                    float bm = 0;
+                    for (int i = 0; i < G::A; i++) {
+                        if (sN[i] < 0) continue;
+                        if (ba < 0 || sN[i] > bc || (sN[i] == bc && (sQ[i] > bm || (sQ[i] == bm && i > ba)))) {
+                            bc = sN[i]; bm = sQ[i]; ba = i;
+                        }
+                    }
+                    selected = ba;
+                }
+            }
+            selected = __shfl(selected, 0);
+            err = __shfl(err, 0);
+            if (err) { fail(err); break; }
+            if (st.temperature == 1) st.i_uniform++;
+            // move_data record
+            int ri = 0;
+            if (lane == 0) ri = atomicAdd(&c.counters->rec_count, 1);
+            ri = __shfl(ri, 0);
+            if (ri >= c.rec_cap) { fail(SGO_ERR_CAPACITY); break; }
+            if (lane == 0) {
+                sgo_move_record r;
+                r.game = g; r.game_seq = st.game_seq; r.move_n = st.move_n; r.action = selected;
+                r.player = st.player; r.value = st.value;
+                c.recs[ri] = r;
+                atomicAdd(&c.counters->total_moves, 1ull);
+            }
+            for (int i = lane; i < G::RW; i += 64) c.recPacked[(size_t)ri * G::RW + i] = c.pos[(e.gb0 + st.root_blk) * G::RW + i];
+            for (int i = lane; i < G::A; i += 64) {
+                double p = 0;
+                if (e.legal_bit(st.root_blk, i)) p = st.root_f64 ? c.rootP64[(size_t)g * G::APAD + i] : (double)c.cP[sb + i];
+                c.recPolicy[(size_t)ri * G::A + i] = p;
+            }
+            st.n_moves = st.move_n + 1;
+            const bool is_pass = (selected == G::N);
+            if (st.skipped_last && is_pass) { st.move_n += 0; finish(2); st.n_moves = st.move_n + 1; break; }
+            st.skipped_last = is_pass ? 1 : 0;
+            // re-root onto the chosen child, recycle every block that is no longer reachable
+            int nr = 0;
+            if (lane == (selected & 63)) nr = c.cB[sb + selected];
+            nr = __shfl(nr, selected & 63);
+            if (nr < 0) { fail(SGO_ERR_STATE); break; }
+            float rv = 0, rm = 0; int rc = 0;
+            if (lane == (selected & 63)) { rc = c.cN[sb + selected]; rv = c.cW[sb + selected]; rm = c.cQ[sb + selected]; }
+            st.root_count = __shfl(rc, selected & 63);
+            st.root_value = __shfl(rv, selected & 63);
+            st.root_mean = __shfl(rm, selected & 63);
+            const int mover = (c.pos[(e.gb0 + st.root_blk) * G::RW + G::META] & 1u) ? -1 : 1;
+            st.root_blk = nr;
+            st.root_f64 = 0;
+            if (lane == 0) { c.bParent[e.gb0 + nr] = -1; c.bSlot[e.gb0 + nr] = -1; }
+            // mark: BFS over expanded nodes
+            for (int i = lane; i < (c.cap + 31) / 32; i += 64) marks[i] = 0;
+            if (lane == 0) queue[0] = nr;
+            __syncthreads();
+            int head = 0, tail = 1;
+            while (head < tail) {
+                const int b = queue[head++];
+                const size_t bsb = e.slot_base(b);
+                for (int j0 = 0; j0 < G::APAD; j0 += 64) {
+                    int i = j0 + lane;
+                    int cb = (i < G::APAD && e.legal_bit(b, i)) ? c.cB[bsb + i] : -1;
+                    unsigned long long m = __ballot(cb >= 0);
+                    if (cb >= 0) queue[tail + __popcll(m & ((1ull << lane) - 1ull))] = cb;
+                    tail += __popcll(m);
+                }
+                __syncthreads();
+            }
+            for (int i = lane; i < tail; i += 64) atomicOr(&marks[queue[i] >> 5], 1u << (queue[i] & 31));
+            __syncthreads();
+            int ft = 0;
+            for (int b0 = 0; b0 < c.cap; b0 += 64) {
+                int b = b0 + lane;
+                bool fr = b < c.cap && !((marks[b >> 5] >> (b & 31)) & 1u);
+                unsigned long long m = __ballot(fr);
+                if (fr) c.freeList[(size_t)g * c.cap + ft + __popcll(m & ((1ull << lane) - 1ull))] = b;
+                ft += __popcll(m);
+            }
+            st.free_top = ft;
+            __syncthreads();
+            // board, player = make_play(...): the new root block already holds the position after the move
+            st.player = mover;
+            st.move_n++;
+            if (st.move_n >= c.max_moves) { finish(0); break; }
+            st.last_value = st.value;
+            if (st.move_n == c.cfg.stop_exploration) st.temperature = 0;
+            st.phase = PH_WAIT_ROOT;
+            st.root_requested = 1;
+            if (lane == 0) c.reqBlk[rbase] = (int32_t)(e.gb0 + st.root_blk);
+            st.n_req = 1;
+            st.req_kind = 0;
+            run = false;
+            break;
+        }
+        if (st.e_left < 0) { st.e_left = c.cfg.energy; st.pre_bp = 0; }
+        bool blocked = false;
+        while (st.e_left > 0) {
+            int pb = -1, slot = -1;
+            bool found = e.find_best_leaf(st, pb, slot);
+            if (found) {
+                int n = 0;
+                if (lane == (slot & 63)) n = c.cN[e.slot_base(pb) + slot];
+                n = __shfl(n, slot & 63);
+                if (n > 0) { st.e_left--; st.pre_bp++; continue; }   // "already simulated leaf node"
+            } else {
+                st.none_events++;
+                if (lane == 0) atomicAdd(&c.counters->none_events, 1ull);
+                if (st.fifo_tail == st.fifo_head) { fail(SGO_ERR_STATE); break; }  // the reference would block forever
+                if (!c.fEvaluated[fbase + (st.fifo_head % (2 * MAXE))]) { st.need_bp = 1; blocked = true; break; }
+                e.back_propagate(st, st.fifo_head % (2 * MAXE));
+                st.fifo_head++;
+                st.pre_bp++;
+                continue;
+            }
+            if (st.free_top <= 0) { fail(SGO_ERR_CAPACITY); break; }
+            const int nb = c.freeList[(size_t)g * c.cap + st.free_top - 1];
+            st.free_top--;
+            const size_t fo = fbase + (st.fifo_tail % (2 * MAXE));
+            if (lane == 0) {
+                c.bParent[e.gb0 + nb] = pb;
+                c.bSlot[e.gb0 + nb] = slot;
+                c.fParent[fo] = pb; c.fSlot[fo] = slot; c.fBlk[fo] = nb;
+                c.fEvalLocal[fo] = st.n_req; c.fEvaluated[fo] = 0;
+                c.reqBlk[rbase + st.n_req] = (int32_t)(e.gb0 + nb);
+                c.reqParent[rbase + st.n_req] = (int32_t)(e.gb0 + pb);
+                c.reqMove[rbase + st.n_req] = slot;
+            }
+            st.fifo_tail++;
+            st.n_req++;
+            st.req_kind = 1;
+            st.e_left--;
+        }
+        __syncthreads();
+        if (!run || blocked) break;
+        bool pending = false;
+        for (int fi = st.fifo_head; fi < st.fifo_tail; fi++)
+            if (!c.fEvaluated[fbase + (fi % (2 * MAXE))]) pending = true;
+        if (pending) break;
+        const int nbp = c.cfg.energy - st.pre_bp;
+        bool bad = false;
+        for (int i = 0; i < nbp; i++) {
+            if (st.fifo_head == st.fifo_tail) { bad = true; break; }
+            e.back_propagate(st, st.fifo_head % (2 * MAXE));
+            st.fifo_head++;
+        }
+        if (bad) { fail(SGO_ERR_STATE); break; }
+        st.e_left = -1;
+        st.rounds_left--;
+    }
+    if (lane == 0) c.gs[g] = st;
+}
+
+// ---------------------------------------------------------------------------------------- k_compact
+// One block.  Exclusive prefix sums of the per-game request counts -> dense evaluation list (block ids
+// in game-major order) and dense leaf list for board_advance; also folds the status words.
+__global__ __launch_bounds__(1024) void k_compact(Ctx c) {
+    __shared__ int sE[1024], sL[1024];
+    __shared__ int sAct[1024], sDone[1024], sErr[1024];
+    const int t = threadIdx.x;
+    const int per = (c.G + 1023) / 1024;
+    const int g0 = t * per, g1 = min(c.G, g0 + per);
+    int ne = 0, nl = 0, act = 0, done = 0, err = 0x7fffffff;
+    for (int g = g0; g < g1; g++) {
+        const GameState &s = c.gs[g];
+        ne += s.n_req;
+        if (s.req_kind == 1) nl += s.n_req;
+        if (s.phase == PH_WAIT_ROOT || s.phase == PH_SEARCH) act++;
+        if (s.phase == PH_DONE) done++;
+        if (s.error && err == 0x7fffffff) err = g;
+    }
+    sE[t] = ne; sL[t] = nl; sAct[t] = act; sDone[t] = done; sErr[t] = err;
+    __syncthreads();
+    // Hillis-Steele inclusive scan
+    for (int o = 1; o < 1024; o <<= 1) {
+        int ve = (t >= o) ? sE[t - o] : 0, vl = (t >= o) ? sL[t - o] : 0;
+        int va = (t >= o) ? sAct[t - o] : 0, vd = (t >= o) ? sDone[t - o] : 0;
+        int vr = (t >= o) ? sErr[t - o] : 0x7fffffff;
+        __syncthreads();
+        sE[t] += ve; sL[t] += vl; sAct[t] += va; sDone[t] += vd; sErr[t] = min(sErr[t], vr);
+        __syncthreads();
+    }
+    int be = sE[t] - ne, bl = sL[t] - nl;
+    for (int g = g0; g < g1; g++) {
+        GameState &s = c.gs[g];
+        s.eval_base = be;
+        for (int j = 0; j < s.n_req; j++) {
+            c.evalIdx[be + j] = c.reqBlk[(size_t)g * c.E + j];
+            if (s.req_kind == 1) {
+                c.leafIn[bl + j] = c.reqParent[(size_t)g * c.E + j];
+                c.leafMv[bl + j] = c.reqMove[(size_t)g * c.E + j];
+                c.leafOut[bl + j] = c.reqBlk[(size_t)g * c.E + j];
+            }
+        }
+        be += s.n_req;
+        if (s.req_kind == 1) bl += s.n_req;
+    }
+    if (t == 1023) {
+        DevStatus d;
+        d.n_eval = sE[1023]; d.n_leaf = sL[1023]; d.n_records = c.counters->rec_count;
+        d.n_active = sAct[1023]; d.n_done = sDone[1023];
+        int eg = sErr[1023];
+        d.error_game = (eg == 0x7fffffff) ? -1 : eg;
+        d.error = (eg == 0x7fffffff) ? 0 : c.gs[eg].error;
+        d.pad = 0;
+        d.total_moves = c.counters->total_moves; d.total_evals = c.counters->total_evals;
+        d.none_events = c.counters->none_events;
+        *c.dstatus = d;
+    }
+}
+
+// board_advance over the compacted leaf list; the launch is sized for the worst case and guarded by
+// the device-side count so that no host round trip sits between k_compact and this kernel.
+template <int S>
+__global__ __launch_bounds__(64) void k_leaf_advance(Ctx c) {
+    using G = Geo<S>;
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= c.dstatus->n_leaf) return;
+    const uint32_t *src = c.pos + (size_t)c.leafIn[i] * G::RW;
+    uint32_t *dst = c.pos + (size_t)c.leafOut[i] * G::RW;
+    uint32_t *lg = c.legal + (size_t)c.leafOut[i] * G::NW;
+    advance_record<S>(src, dst, c.leafMv[i], false, lg);
+}
+
+// (re)start listed game slots: empty board in block 0, everything else free
+template <int S>
+__global__ __launch_bounds__(64) void k_start(Ctx c, int n, const float *resign) {
+    using G = Geo<S>;
+    const int k = blockIdx.x;
+    if (k >= n) return;
+    const int g = c.slotList[k];
+    const int lane = threadIdx.x;
+    const size_t gb0 = (size_t)g * c.cap;
+    GameState st;
+    memset(&st, 0, sizeof st);
+    st.phase = PH_WAIT_ROOT;
+    st.root_blk = 0;
+    st.player = 1;
+    st.temperature = (0 == c.cfg.stop_exploration) ? 0 : 1;
+    st.e_left = -1;
+    st.halt_at = -1;
+    st.n_uniform = c.max_moves;
+    st.game_seq = c.gs[g].phase == PH_IDLE && c.gs[g].game_seq == 0 && c.gs[g].n_predict == 0 ? 0 : c.gs[g].game_seq + 1;
+    float r = resign ? resign[k] : NAN;
+    st.has_resign = !(r != r);
+    st.resign = st.has_resign ? r : 0.f;
+    if (c.max_moves == 0) st.phase = PH_DONE;
+    for (int i = lane; i < G::RW; i += 64) c.pos[gb0 * G::RW + i] = 0;
+    for (int i = lane; i < G::NW; i += 64) {
+        uint32_t w = 0xffffffffu;
+        if (i == G::NW - 1) {
+            int bits = G::A - 32 * (G::NW - 1);
+            w = (bits >= 32) ? 0xffffffffu : ((1u << bits) - 1u);
+        }
+        c.legal[gb0 * G::NW + i] = w;
+    }
+    for (int b = lane; b < c.cap - 1; b += 64) c.freeList[(size_t)g * c.cap + b] = c.cap - 1 - b;  // pops give 1,2,3,...
+    st.free_top = c.cap - 1;
+    if (lane == 0) {
+        c.bParent[gb0] = -1;
+        c.bSlot[gb0] = -2;  // no children yet
+        c.gs[g] = st;
+    }
+}
+
+template <int S>
+static size_t search_lds(const Ctx &c) {
+    return sizeof(int32_t) * ((size_t)c.cap + 2 * Geo<S>::APAD + (c.cap + 31) / 32 + 4);
+}
+
+}  // namespace sgo
+
+using namespace sgo;
+
+struct sgo_ctx {
+    Ctx c;
+    HostSide h;
+};
+
+#define CK(call)                      \
+    do {                              \
+        int _r = (call);              \
+        if (_r != SGO_OK) return _r;  \
+    } while (0)
+
+template <typename T>
+static int dalloc(T **p, size_t n) {
+    SGO_HIP(hipMalloc((void **)p, sizeof(T) * (n ? n : 1)));
+    SGO_HIP(hipMemset(*p, 0, sizeof(T) * (n ? n : 1)));
+    return SGO_OK;
+}
+
+static int ctx_alloc(Ctx &c) {
+    const size_t nb = (size_t)c.G * c.cap;
+    CK(dalloc(&c.gs, c.G));
+    CK(dalloc(&c.pos, nb * c.RW));
+    CK(dalloc(&c.legal, nb * c.NW));
+    CK(dalloc(&c.cP, nb * c.APAD));
+    CK(dalloc(&c.cW, nb * c.APAD));
+    CK(dalloc(&c.cQ, nb * c.APAD));
+    CK(dalloc(&c.cN, nb * c.APAD));
+    CK(dalloc(&c.cB, nb * c.APAD));
+    CK(dalloc(&c.cBusy, nb * c.APAD));
+    CK(dalloc(&c.bParent, nb));
+    CK(dalloc(&c.bSlot, nb));
+    CK(dalloc(&c.freeList, nb));
+    CK(dalloc(&c.rootP64, (size_t)c.G * c.APAD));
+    CK(dalloc(&c.noise, (size_t)c.G * c.APAD));
+    CK(dalloc(&c.uniforms, (size_t)c.G * (c.max_moves ? c.max_moves : 1)));
+    const size_t nf = (size_t)c.G * 2 * MAXE;
+    CK(dalloc(&c.fParent, nf));
+    CK(dalloc(&c.fSlot, nf));
+    CK(dalloc(&c.fBlk, nf));
+    CK(dalloc(&c.fEvalLocal, nf));
+    CK(dalloc(&c.fEvaluated, nf));
+    CK(dalloc(&c.fValue, nf));
+    const size_t nr = (size_t)c.G * c.E;
+    CK(dalloc(&c.reqBlk, nr));
+    CK(dalloc(&c.reqParent, nr));
+    CK(dalloc(&c.reqMove, nr));
+    CK(dalloc(&c.evalIdx, nr));
+    CK(dalloc(&c.leafIn, nr));
+    CK(dalloc(&c.leafMv, nr));
+    CK(dalloc(&c.leafOut, nr));
+    CK(dalloc(&c.recs, (size_t)c.rec_cap));
+    CK(dalloc(&c.recPacked, (size_t)c.rec_cap * c.RW));
+    CK(dalloc(&c.recPolicy, (size_t)c.rec_cap * c.A));
+    CK(dalloc(&c.counters, 1));
+    CK(dalloc(&c.dstatus, 1));
+    CK(dalloc(&c.symLut, (size_t)8 * c.A));
+    CK(dalloc(&c.slotList, c.G));
+    SGO_HIP(hipHostMalloc((void **)&c.hstatus, sizeof(DevStatus), hipHostMallocDefault));
+    memset(c.hstatus, 0, sizeof(DevStatus));
+    std::vector<int32_t> lut((size_t)8 * c.A);
+    for (int k = 0; k < 8; k++) build_sym_lut(c.S, k, lut.data() + (size_t)k * c.A);
+    SGO_HIP(hipMemcpy(c.symLut, lut.data(), sizeof(int32_t) * lut.size(), hipMemcpyHostToDevice));
+    return SGO_OK;
+}
+
+static void ctx_free(Ctx &c) {
+    void *ptrs[] = {c.gs, c.pos, c.legal, c.cP, c.cW, c.cQ, c.cN, c.cB, c.cBusy, c.bParent, c.bSlot, c.freeList,
+                    c.rootP64, c.noise, c.uniforms, c.fParent, c.fSlot, c.fBlk, c.fEvalLocal, c.fEvaluated, c.fValue,
+                    c.reqBlk, c.reqParent, c.reqMove, c.evalIdx, c.leafIn, c.leafMv, c.leafOut, c.recs, c.recPacked,
+                    c.recPolicy, c.counters, c.dstatus, c.symLut, c.slotList};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    if (c.hstatus) (void)hipHostFree(c.hstatus);
+}
+
+extern "C" {
+
+sgo_ctx *sgo_ctx_create(const sgo_config *cfg) {
+    if (!cfg || !size_ok(cfg->size) || cfg->n_games < 1 || cfg->energy < 1 || cfg->energy > MAXE || cfg->sims < 0) {
+        set_error("sgo_ctx_create: bad config");
+        return nullptr;
+    }
+    if (hipSetDevice(cfg->device_id) != hipSuccess) { set_error("sgo_ctx_create: hipSetDevice failed (no HIP device?)"); return nullptr; }
+    sgo_ctx *x = new sgo_ctx();
+    Ctx &c = x->c;
+    memset((void *)&c.cfg, 0, sizeof c.cfg);
+    c.cfg = *cfg;
+    c.S = cfg->size; c.A = c.S * c.S + 1; c.NW = sgo_plane_words(c.S); c.RW = sgo_packed_words(c.S);
+    c.APAD = 32 * c.NW; c.G = cfg->n_games; c.E = cfg->energy;
+    c.cap = cfg->blocks_per_game > 0 ? cfg->blocks_per_game : 3 * cfg->sims + 64;
+    if (c.cap < cfg->energy + 2) c.cap = cfg->energy + 2;
+    c.max_moves = cfg->num_moves < 0 ? 2 * c.S * c.S : cfg->num_moves;
+    c.rec_cap = 2 * c.G + 16;
+    c.last_n_eval = 0;
+    c.gs = nullptr; c.hstatus = nullptr;
+    // LDS budget of k_search: queue[cap] + sN/sQ + marks
+    size_t lds = sizeof(int32_t) * ((size_t)c.cap + 2 * c.APAD + (c.cap + 31) / 32 + 4);
+    if (lds > 160 * 1024) { set_error("sgo_ctx_create: blocks_per_game too large for the LDS work queue"); delete x; return nullptr; }
+    if (ctx_alloc(c) != SGO_OK) { ctx_free(c); delete x; return nullptr; }
+    if (hipEventCreate(&x->h.ev0) != hipSuccess || hipEventCreate(&x->h.ev1) != hipSuccess) {
+        set_error("sgo_ctx_create: hipEventCreate failed");
+        ctx_free(c); delete x; return nullptr;
+    }
+    return x;
+}
+
+void sgo_ctx_destroy(sgo_ctx *x) {
+    if (!x) return;
+    (void)hipSetDevice(x->c.cfg.device_id);
+    (void)hipDeviceSynchronize();
+    ctx_free(x->c);
+    if (x->h.ev0) (void)hipEventDestroy(x->h.ev0);
+    if (x->h.ev1) (void)hipEventDestroy(x->h.ev1);
+    delete x;
+}
+
+int sgo_start_games(sgo_ctx *x, int n, const int32_t *slots, const double *noise, const double *uniforms, int n_uniforms,
+                    const float *resign) {
+    if (!x || n < 0 || (n && !slots)) { set_error("sgo_start_games: bad argument"); return SGO_ERR_ARG; }
+    Ctx &c = x->c;
+    if (n == 0) return SGO_OK;
+    if (n > c.G || n_uniforms < 0) { set_error("sgo_start_games: too many slots"); return SGO_ERR_ARG; }
+    SGO_HIP(hipSetDevice(c.cfg.device_id));
+    SGO_HIP(hipDeviceSynchronize());
+    for (int i = 0; i < n; i++)
+        if (slots[i] < 0 || slots[i] >= c.G) { set_error("sgo_start_games: slot out of range"); return SGO_ERR_ARG; }
+    SGO_HIP(hipMemcpy(c.slotList, slots, sizeof(int32_t) * n, hipMemcpyHostToDevice));
+    const int nu = n_uniforms < c.max_moves ? n_uniforms : c.max_moves;
+    for (int i = 0; i < n; i++) {
+        if (noise) {
+            std::vector<double> row(c.APAD, 0.0);
+            memcpy(row.data(), noise + (size_t)i * c.A, sizeof(double) * c.A);
+            SGO_HIP(hipMemcpy(c.noise + (size_t)slots[i] * c.APAD, row.data(), sizeof(double) * c.APAD, hipMemcpyHostToDevice));
+        }
+        if (uniforms && nu > 0)
+            SGO_HIP(hipMemcpy(c.uniforms + (size_t)slots[i] * c.max_moves, uniforms + (size_t)i * n_uniforms, sizeof(double) * nu,
+                              hipMemcpyHostToDevice));
+    }
+    float *d_res = nullptr;
+    if (resign) {
+        SGO_HIP(hipMalloc((void **)&d_res, sizeof(float) * n));
+        SGO_HIP(hipMemcpy(d_res, resign, sizeof(float) * n, hipMemcpyHostToDevice));
+    }
+    SGO_DISPATCH(c.S, k_start<kS><<<dim3(n), dim3(64), 0, nullptr>>>(c, n, d_res));
+    SGO_HIP(hipGetLastError());
+    SGO_HIP(hipDeviceSynchronize());
+    if (d_res) (void)hipFree(d_res);
+    if (!uniforms || nu < c.max_moves) {
+        // games that sample a move without a supplied draw fail with SGO_ERR_DRAWS: record how many were given
+        std::vector<GameState> tmp(1);
+        for (int i = 0; i < n; i++) {
+            SGO_HIP(hipMemcpy(tmp.data(), c.gs + slots[i], sizeof(GameState), hipMemcpyDeviceToHost));
+            tmp[0].n_uniform = uniforms ? nu : 0;
+            SGO_HIP(hipMemcpy(c.gs + slots[i], tmp.data(), sizeof(GameState), hipMemcpyHostToDevice));
+        }
+    }
+    return SGO_OK;
+}
+
+int sgo_step(sgo_ctx *x, const float *d_policy, const float *d_value, int sym_k, void *stream, sgo_status *out) {
+    if (!x || !out || sym_k < 0 || sym_k > 7) { set_error("sgo_step: bad argument"); return SGO_ERR_ARG; }
+    Ctx &c = x->c;
+    hipStream_t st = (hipStream_t)stream;
+    if (c.last_n_eval > 0 && (!d_policy || !d_value)) {
+        set_error("sgo_step: the previous step listed positions to evaluate; policy/value are required");
+        return SGO_ERR_STATE;
+    }
+    SGO_DISPATCH(c.S, {
+        const size_t lds = search_lds<kS>(c);
+        if (lds > 64 * 1024)
+            SGO_HIP(hipFuncSetAttribute((const void *)k_search<kS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        k_search<kS><<<dim3(c.G), dim3(64), lds, st>>>(c, d_policy, d_value, sym_k);
+    });
+    SGO_HIP(hipGetLastError());
+    k_compact<<<dim3(1), dim3(1024), 0, st>>>(c);
+    SGO_HIP(hipGetLastError());
+    // board_advance for the new leaves, bracketed by HIP events on this stream
+    SGO_HIP(hipEventRecord(x->h.ev0, st));
+    const int max_leaf = c.G * c.E;
+    SGO_DISPATCH(c.S, k_leaf_advance<kS><<<dim3((max_leaf + 63) / 64), dim3(64), 0, st>>>(c));
+    SGO_HIP(hipGetLastError());
+    SGO_HIP(hipEventRecord(x->h.ev1, st));
+    SGO_HIP(hipMemcpyAsync(c.hstatus, c.dstatus, sizeof(DevStatus), hipMemcpyDeviceToHost, st));
+    SGO_HIP(hipStreamSynchronize(st));
+    const DevStatus &d = *c.hstatus;
+    if (d.n_leaf > 0) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, x->h.ev0, x->h.ev1) == hipSuccess) {
+            x->h.adv_ms += ms; x->h.adv_launches += 1; x->h.adv_positions += d.n_leaf;
+        }
+    }
+    out->n_eval = d.n_eval; out->n_records = d.n_records; out->n_active = d.n_active; out->n_done = d.n_done;
+    out->error = d.error; out->error_game = d.error_game; out->total_moves = (int64_t)d.total_moves;
+    out->total_evals = (int64_t)d.total_evals; out->none_events = (int64_t)d.none_events;
+    c.last_n_eval = d.n_eval;
+    return SGO_OK;
+}
+
+int sgo_collect(sgo_ctx *x, int sym_k, int layout, int dtype, void *d_nn_in, void *stream) {
+    if (!x || !d_nn_in) { set_error("sgo_collect: bad argument"); return SGO_ERR_ARG; }
+    Ctx &c = x->c;
+    if (sym_k < 0 || sym_k > 7 || layout < 0 || layout > 1 || dtype < 0 || dtype > 1) { set_error("sgo_collect: bad argument"); return SGO_ERR_ARG; }
+    return launch_nn_pack(c.S, c.last_n_eval, c.pos, c.evalIdx, sym_k, layout, dtype, d_nn_in, (hipStream_t)stream);
+}
+
+int sgo_drain_records(sgo_ctx *x, int cap, sgo_move_record *recs, uint32_t *packed, double *policy) {
+    if (!x || cap < 0) { set_error("sgo_drain_records: bad argument"); return SGO_ERR_ARG; }
+    Ctx &c = x->c;
+    SGO_HIP(hipDeviceSynchronize());
+    Counters h;
+    SGO_HIP(hipMemcpy(&h, c.counters, sizeof h, hipMemcpyDeviceToHost));
+    int n = h.rec_count;
+    if (n > c.rec_cap) n = c.rec_cap;
+    if (n > cap) { set_error("sgo_drain_records: caller buffer too small"); return SGO_ERR_ARG; }
+    if (n > 0) {
+        if (recs) SGO_HIP(hipMemcpy(recs, c.recs, sizeof(sgo_move_record) * n, hipMemcpyDeviceToHost));
+        if (packed) SGO_HIP(hipMemcpy(packed, c.recPacked, sizeof(uint32_t) * (size_t)n * c.RW, hipMemcpyDeviceToHost));
+        if (policy) SGO_HIP(hipMemcpy(policy, c.recPolicy, sizeof(double) * (size_t)n * c.A, hipMemcpyDeviceToHost));
+    }
+    int zero = 0;
+    SGO_HIP(hipMemcpy(&c.counters->rec_count, &zero, sizeof zero, hipMemcpyHostToDevice));
+    return n;
+}
+
+int sgo_game_results(sgo_ctx *x, int n, const int32_t *slots, sgo_game_result *out) {
+    if (!x || n < 0 || !out) { set_error("sgo_game_results: bad argument"); return SGO_ERR_ARG; }
+    Ctx &c = x->c;
+    SGO_HIP(hipDeviceSynchronize());
+    std::vector<GameState> all(c.G);
+    SGO_HIP(hipMemcpy(all.data(), c.gs, sizeof(GameState) * c.G, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; i++) {
+        int g = slots ? slots[i] : i;
+        if (g < 0 || g >= c.G) { set_error("sgo_game_results: slot out of range"); return SGO_ERR_ARG; }
+        const GameState &s = all[g];
+        out[i].winner = s.winner; out[i].black = s.black; out[i].white = s.white; out[i].end_reason = s.end_reason;
+        out[i].n_moves = s.n_moves; out[i].last_player = s.last_player; out[i].done = (s.phase == PH_DONE) ? 1 : 0;
+        if (s.error) out[i].done = s.error;
+    }
+    return SGO_OK;
+}
+
+int sgo_set_halt(sgo_ctx *x, int slot, int move_n) {
+    if (!x || slot < 0 || slot >= x->c.G) { set_error("sgo_set_halt: bad argument"); return SGO_ERR_ARG; }
+    Ctx &c = x->c;
+    SGO_HIP(hipDeviceSynchronize());
+    GameState s;
+    SGO_HIP(hipMemcpy(&s, c.gs + slot, sizeof s, hipMemcpyDeviceToHost));
+    s.halt_at = move_n;
+    SGO_HIP(hipMemcpy(c.gs + slot, &s, sizeof s, hipMemcpyHostToDevice));
+    return SGO_OK;
+}
+
+// ---- introspection (host side walks a snapshot of one game's blocks)
+struct Snap {
+    GameState s;
+    std::vector<float> P, W, Q;
+    std::vector<int32_t> N, B;
+    std::vector<uint8_t> busy;
+    std::vector<uint32_t> legal;
+    std::vector<double> p64;
+};
+static int snapshot(Ctx &c, int g, Snap &sn) {
+    SGO_HIP(hipDeviceSynchronize());
+    SGO_HIP(hipMemcpy(&sn.s, c.gs + g, sizeof(GameState), hipMemcpyDeviceToHost));
+    const size_t nb = c.cap, ns = nb * c.APAD, off = (size_t)g * c.cap;
+    sn.P.resize(ns); sn.W.resize(ns); sn.Q.resize(ns); sn.N.resize(ns); sn.B.resize(ns); sn.busy.resize(ns);
+    sn.legal.resize(nb * c.NW); sn.p64.resize(c.APAD);
+    SGO_HIP(hipMemcpy(sn.P.data(), c.cP + off * c.APAD, sizeof(float) * ns, hipMemcpyDeviceToHost));
+    SGO_HIP(hipMemcpy(sn.W.data(), c.cW + off * c.APAD, sizeof(float) * ns, hipMemcpyDeviceToHost));
+    SGO_HIP(hipMemcpy(sn.Q.data(), c.cQ + off * c.APAD, sizeof(float) * ns, hipMemcpyDeviceToHost));
+    SGO_HIP(hipMemcpy(sn.N.data(), c.cN + off * c.APAD, sizeof(int32_t) * ns, hipMemcpyDeviceToHost));
+    SGO_HIP(hipMemcpy(sn.B.data(), c.cB + off * c.APAD, sizeof(int32_t) * ns, hipMemcpyDeviceToHost));
+    SGO_HIP(hipMemcpy(sn.busy.data(), c.cBusy + off * c.APAD, ns, hipMemcpyDeviceToHost));
+    SGO_HIP(hipMemcpy(sn.legal.data(), c.legal + off * c.NW, sizeof(uint32_t) * nb * c.NW, hipMemcpyDeviceToHost));
+    SGO_HIP(hipMemcpy(sn.p64.data(), c.rootP64 + (size_t)g * c.APAD, sizeof(double) * c.APAD, hipMemcpyDeviceToHost));
+    return SGO_OK;
+}
+static bool snap_exists(const Ctx &c, const Snap &sn, int blk, int i) {
+    return (sn.legal[(size_t)blk * c.NW + (i >> 5)] >> (i & 31)) & 1u;
+}
+
+int sgo_root_table(sgo_ctx *x, int slot, int32_t *N, float *W, float *Q, double *P, int8_t *EX, int32_t *root_count,
+                   float *root_value) {
+    if (!x || slot < 0 || slot >= x->c.G) { set_error("sgo_root_table: bad argument"); return SGO_ERR_ARG; }
+    Ctx &c = x->c;
+    Snap sn;
+    CK(snapshot(c, slot, sn));
+    const int rb = sn.s.root_blk;
+    std::vector<int32_t> bslot(1);
+    SGO_HIP(hipMemcpy(bslot.data(), c.bSlot + (size_t)slot * c.cap + rb, sizeof(int32_t), hipMemcpyDeviceToHost));
+    const bool expanded = bslot[0] != -2;
+    for (int a = 0; a < c.A; a++) {
+        const size_t o = (size_t)rb * c.APAD + a;
+        bool ex = expanded && snap_exists(c, sn, rb, a);
+        if (N) N[a] = ex ? sn.N[o] : 0;
+        if (W) W[a] = ex ? sn.W[o] : 0;
+        if (Q) Q[a] = ex ? sn.Q[o] : 0;
+        if (P) P[a] = ex ? (sn.s.root_f64 ? sn.p64[a] : (double)sn.P[o]) : 0;
+        if (EX) EX[a] = ex ? 1 : 0;
+    }
+    if (root_count) *root_count = sn.s.root_count;
+    if (root_value) *root_value = sn.s.root_value;
+    return SGO_OK;
+}
+
+static void ser_rec(const Ctx &c, const Snap &sn, int blk, bool f64, uint8_t *buf, int64_t cap, int64_t &off, int64_t &nn,
+                    int64_t &ne) {
+    for (int a = 0; a < c.A; a++) {
+        if (!snap_exists(c, sn, blk, a)) continue;
+        const size_t o = (size_t)blk * c.APAD + a;
+        const int32_t cb = sn.B[o];
+        if (buf && off + 32 <= cap) {
+            int32_t i32;
+            double p = f64 ? sn.p64[a] : (double)sn.P[o];
+            i32 = a; memcpy(buf + off, &i32, 4);
+            i32 = sn.N[o]; memcpy(buf + off + 4, &i32, 4);
+            memcpy(buf + off + 8, &sn.W[o], 4);
+            memcpy(buf + off + 12, &sn.Q[o], 4);
+            memcpy(buf + off + 16, &p, 8);
+            i32 = sn.busy[o]; memcpy(buf + off + 24, &i32, 4);
+            i32 = cb >= 0 ? 1 : 0; memcpy(buf + off + 28, &i32, 4);
+        }
+        off += 32;
+        nn++;
+        if (cb >= 0) { ne++; ser_rec(c, sn, cb, false, buf, cap, off, nn, ne); }
+    }
+}
+
+int64_t sgo_tree_serialize(sgo_ctx *x, int slot, uint8_t *buf, int64_t cap, int64_t *n_nodes, int64_t *n_expanded) {
+    if (!x || slot < 0 || slot >= x->c.G) { set_error("sgo_tree_serialize: bad argument"); return SGO_ERR_ARG; }
+    Ctx &c = x->c;
+    Snap sn;
+    CK(snapshot(c, slot, sn));
+    int32_t bslot = 0;
+    SGO_HIP(hipMemcpy(&bslot, c.bSlot + (size_t)slot * c.cap + sn.s.root_blk, sizeof(int32_t), hipMemcpyDeviceToHost));
+    int64_t off = 0, nn = 0, ne = 0;
+    if (bslot != -2) ser_rec(c, sn, sn.s.root_blk, sn.s.root_f64 != 0, buf, cap, off, nn, ne);
+    if (n_nodes) *n_nodes = nn;
+    if (n_expanded) *n_expanded = ne;
+    return off;
+}
+
+int sgo_game_board(sgo_ctx *x, int slot, int32_t *board17) {
+    if (!x || slot < 0 || slot >= x->c.G || !board17) { set_error("sgo_game_board: bad argument"); return SGO_ERR_ARG; }
+    Ctx &c = x->c;
+    SGO_HIP(hipDeviceSynchronize());
+    GameState s;
+    SGO_HIP(hipMemcpy(&s, c.gs + slot, sizeof s, hipMemcpyDeviceToHost));
+    int32_t *d = nullptr;
+    const size_t bsz = sizeof(int32_t) * (size_t)c.S * c.S * 17;
+    SGO_HIP(hipMalloc((void **)&d, bsz));
+    int r = sgo_unpack_dev(c.S, 1, c.pos + ((size_t)slot * c.cap + s.root_blk) * c.RW, d, nullptr);
+    if (r == SGO_OK) {
+        hipError_t e = hipMemcpy(board17, d, bsz, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) r = hip_fail(e, "hipMemcpy", __FILE__, __LINE__);
+    }
+    (void)hipFree(d);
+    return r;
+}
+
+int sgo_advance_timing(sgo_ctx *x, double *total_ms, int64_t *launches, int64_t *positions) {
+    if (!x) { set_error("sgo_advance_timing: bad argument"); return SGO_ERR_ARG; }
+    if (total_ms) *total_ms = x->h.adv_ms;
+    if (launches) *launches = x->h.adv_launches;
+    if (positions) *positions = x->h.adv_positions;
+    x->h.adv_ms = 0; x->h.adv_launches = 0; x->h.adv_positions = 0;
+    return SGO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,459 @@
+// sgo_rules.hip -- batch Go-rules kernels for gfx950 and the stateless half of the C ABI (include/sgo.h).
+//
+// Kernels (all one-lane-per-position unless noted, see sgo_bits.hpp):
+//   k_advance_legal  board_advance: make_play + legal set of the new position      (play.py:226-242, :71-104)
+//   k_legal          legal set of a position                                       (play.py:71-104)
+//   k_score          area score                                                    (play.py:244-292)
+//   k_pack/k_unpack  int32 [S][S][17] board tensor <-> packed bit-planes (one thread per point, ballot)
+//   k_nn_pack        packed position -> fp16/fp32 network input, symmetry fused    (symmetry.py:45-114)
+//   k_sym_apply      symmetry on the raw int32 tensor                              (symmetry.py:45-114)
+//   k_sym_policy     out[a] = in[SWAP[a]]                                          (symmetry.py reverse_*)
+#include <hip/hip_fp16.h>
+#include <math.h>
+#include <mutex>
+#include <string.h>
+#include <vector>
+
+#include "sgo_bits.hpp"
+#include "sgo_common.hpp"
+
+namespace sgo {
+
+// ------------------------------------------------------------------------------------ errors
+static thread_local std::string g_err;
+void set_error(const std::string &msg) { g_err = msg; }
+int hip_fail(hipError_t e, const char *what, const char *file, int line) {
+    char buf[512];
+    snprintf(buf, sizeof buf, "HIP error %d (%s) at %s:%d: %s", (int)e, hipGetErrorString(e), file, line, what);
+    g_err = buf;
+    return SGO_ERR_HIP;
+}
+
+// ------------------------------------------------------------------------------------ symmetry maps
+// transformed[i][j] = source[si][sj]  (row i, column j), symmetry.py:45-114
+__host__ __device__ inline void sym_src(int S, int k, int i, int j, int &si, int &sj) {
+    si = i; sj = j;
+    switch (k) {
+    case 1: si = j; sj = i; break;
+    case 2: sj = S - 1 - j; break;
+    case 3: si = S - 1 - i; break;
+    case 4: si = j; sj = S - 1 - i; break;
+    case 5: si = S - 1 - i; sj = S - 1 - j; break;
+    case 6: si = S - 1 - j; sj = i; break;
+    case 7: si = S - 1 - j; sj = S - 1 - i; break;
+    default: break;
+    }
+}
+
+void build_sym_lut(int S, int k, int32_t *lut) {
+    const double pi = 3.141592653589793;
+    const double c = (S - 1) / 2.0;
+    for (int i = 0; i <= S * S; i++) lut[i] = i;
+    if (k == 0) return;
+    const bool rot = (k >= 4 && k <= 6);
+    double angle = 0;
+    switch (k) {
+    case 1: angle = pi / 4.; break;       // left diagonal   (axis_symmetry_indexes)
+    case 2: angle = pi / 2.; break;       // vertical axis
+    case 3: angle = 0; break;             // horizontal axis
+    case 4: angle = pi / 2.; break;       // rotation_indexes
+    case 5: angle = pi; break;
+    case 6: angle = 3 * pi / 2; break;
+    case 7: angle = 3 * pi / 4.; break;   // right diagonal
+    }
+    for (int x = 0; x < S; x++)
+        for (int y = 0; y < S; y++) {
+            double fx = x - c, fy = y - c, nx, ny;
+            if (rot) {
+                nx = cos(angle) * fx - sin(angle) * fy;
+                ny = sin(angle) * fx + cos(angle) * fy;
+            } else {
+                nx = cos(2 * angle) * fx + sin(2 * angle) * fy;
+                ny = sin(2 * angle) * fx - cos(2 * angle) * fy;
+            }
+            lut[x + S * y] = (int32_t)lrint((nx + c) + S * (ny + c));
+        }
+}
+
+// ------------------------------------------------------------------------------------ kernels
+template <int S>
+__global__ __launch_bounds__(256) void k_advance_legal(int n, const uint32_t *in, const int32_t *in_idx,
+                                                       const int32_t *moves, const int32_t *colors, uint32_t *out,
+                                                       const int32_t *out_idx, uint32_t *legal,
+                                                       const int32_t *legal_idx, int32_t *status) {
+    using G = Geo<S>;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t *src = in + (size_t)(in_idx ? in_idx[i] : i) * G::RW;
+    uint32_t *dst = out + (size_t)(out_idx ? out_idx[i] : i) * G::RW;
+    uint32_t *lg = legal ? legal + (size_t)(legal_idx ? legal_idx[i] : i) * G::NW : nullptr;
+    bool swap_first = false;
+    int mover = (src[G::META] & 1u) ? -1 : 1;
+    if (colors) {
+        int c = colors[i];
+        if (c != 0 && c != mover) { swap_first = true; mover = -mover; }
+    }
+    int st = advance_record<S>(src, dst, moves[i], swap_first, lg);
+    if (status) status[i] = st ? st : mover;
+}
+
+template <int S>
+__global__ __launch_bounds__(256) void k_legal(int n, const uint32_t *packed, const int32_t *idx, uint32_t *legal) {
+    using G = Geo<S>;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    legal_record<S>(packed + (size_t)(idx ? idx[i] : i) * G::RW, legal + (size_t)i * G::NW);
+}
+
+template <int S>
+__global__ __launch_bounds__(256) void k_score(int n, const uint32_t *packed, const int32_t *idx, double komi,
+                                               int32_t *result) {
+    using G = Geo<S>;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int bp, wp;
+    score_record<S>(packed + (size_t)(idx ? idx[i] : i) * G::RW, bp, wp);
+    double white = (double)wp + komi;  // play.py:278
+    int w = ((double)bp > white) ? 1 : (((double)bp == white) ? 0 : -1);
+    result[3 * i] = w;
+    result[3 * i + 1] = bp;
+    result[3 * i + 2] = wp;
+}
+
+// one block per board, one thread per point (rounded up to whole waves); wave ballots build the words
+template <int S>
+__global__ void k_pack(int n, const int32_t *boards, uint32_t *packed) {
+    using G = Geo<S>;
+    int b = blockIdx.x;
+    int t = threadIdx.x;
+    const int32_t *src = boards + (size_t)b * G::N * 17;
+    uint32_t *dst = packed + (size_t)b * G::RW;
+    int wave = t >> 6, lane = t & 63;
+    for (int c = 0; c < 16; c++) {
+        int v = (t < G::N) ? (src[t * 17 + c] != 0) : 0;
+        unsigned long long m = __ballot(v);
+        if (lane == 0) {
+            if (2 * wave < G::NW) dst[c * G::NW + 2 * wave] = (uint32_t)m;
+            if (2 * wave + 1 < G::NW) dst[c * G::NW + 2 * wave + 1] = (uint32_t)(m >> 32);
+        }
+    }
+    if (t == 0) {
+        dst[G::META] = (src[16] == -1) ? 1u : 0u;
+        for (int i = G::META + 1; i < G::RW; i++) dst[i] = 0;
+    }
+}
+
+template <int S>
+__global__ void k_unpack(int n, const uint32_t *packed, int32_t *boards) {
+    using G = Geo<S>;
+    int b = blockIdx.x;
+    int t = threadIdx.x;
+    if (t >= G::N) return;
+    const uint32_t *src = packed + (size_t)b * G::RW;
+    int32_t *dst = boards + ((size_t)b * G::N + t) * 17;
+    for (int c = 0; c < 16; c++) dst[c] = (src[c * G::NW + (t >> 5)] >> (t & 31)) & 1u;
+    dst[16] = (src[G::META] & 1u) ? -1 : 1;
+}
+
+// network input: out[i] = symmetry_k(position idx[i]).  One thread per (entry, point).
+template <int S, typename T>
+__global__ __launch_bounds__(256) void k_nn_pack(int n, const uint32_t *packed, const int32_t *idx, int k, int layout,
+                                                 T *out) {
+    using G = Geo<S>;
+    int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n * G::N) return;
+    int e = gid / G::N, pt = gid - e * G::N;
+    int i = pt / S, j = pt - i * S, si, sj;
+    sym_src(S, k, i, j, si, sj);
+    int sp = si * S + sj;
+    const uint32_t *rec = packed + (size_t)(idx ? idx[e] : e) * G::RW;
+    T vals[17];
+#pragma unroll
+    for (int c = 0; c < 16; c++) vals[c] = (T)(float)((rec[c * G::NW + (sp >> 5)] >> (sp & 31)) & 1u);
+    vals[16] = (T)((rec[G::META] & 1u) ? -1.0f : 1.0f);
+    if (layout == 0) {  // NHWC
+        T *o = out + ((size_t)e * G::N + pt) * 17;
+#pragma unroll
+        for (int c = 0; c < 17; c++) o[c] = vals[c];
+    } else {  // NCHW
+        T *o = out + (size_t)e * 17 * G::N + pt;
+#pragma unroll
+        for (int c = 0; c < 17; c++) o[(size_t)c * G::N] = vals[c];
+    }
+}
+
+__global__ void k_sym_apply(int S, int k, int n, const int32_t *in, int32_t *out) {
+    int N = S * S;
+    int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n * N) return;
+    int b = gid / N, pt = gid - b * N;
+    int i = pt / S, j = pt - i * S, si, sj;
+    sym_src(S, k, i, j, si, sj);
+    const int32_t *s = in + ((size_t)b * N + si * S + sj) * 17;
+    int32_t *d = out + ((size_t)b * N + pt) * 17;
+    for (int c = 0; c < 17; c++) d[c] = s[c];
+}
+
+__global__ void k_sym_policy(int A, int n, const int32_t *lut, const float *in, float *out) {
+    int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n * A) return;
+    int b = gid / A, a = gid - b * A;
+    out[gid] = in[(size_t)b * A + lut[a]];
+}
+
+__global__ void k_legal_to_mask(int A, int NW, int n, const uint32_t *legal, uint8_t *mask) {
+    int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n * A) return;
+    int b = gid / A, a = gid - b * A;
+    uint32_t bit = (legal[(size_t)b * NW + (a >> 5)] >> (a & 31)) & 1u;
+    mask[gid] = bit ? 0 : 1;  // the reference's mask: 1 = illegal
+}
+
+// ------------------------------------------------------------------------------------ launchers
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+int launch_advance_legal(int S, int n, const uint32_t *d_in, const int32_t *d_in_idx, const int32_t *d_moves,
+                         const int32_t *d_colors, uint32_t *d_out, const int32_t *d_out_idx, uint32_t *d_legal,
+                         const int32_t *d_legal_idx, int32_t *d_status, hipStream_t st) {
+    if (n <= 0) return SGO_OK;
+    // 64-thread blocks: a block is one wavefront = 64 positions, so small batches still spread over CUs
+    SGO_DISPATCH(S, k_advance_legal<kS><<<dim3(cdiv(n, 64)), dim3(64), 0, st>>>(n, d_in, d_in_idx, d_moves, d_colors, d_out, d_out_idx, d_legal, d_legal_idx, d_status));
+    SGO_HIP(hipGetLastError());
+    return SGO_OK;
+}
+int launch_nn_pack(int S, int n, const uint32_t *d_packed, const int32_t *d_idx, int k, int layout, int dtype,
+                   void *d_out, hipStream_t st) {
+    if (n <= 0) return SGO_OK;
+    if (dtype == 0) {
+        SGO_DISPATCH(S, k_nn_pack<kS, __half><<<dim3(cdiv((long)n * kS * kS, 256)), dim3(256), 0, st>>>(n, d_packed, d_idx, k, layout, (__half *)d_out));
+    } else {
+        SGO_DISPATCH(S, k_nn_pack<kS, float><<<dim3(cdiv((long)n * kS * kS, 256)), dim3(256), 0, st>>>(n, d_packed, d_idx, k, layout, (float *)d_out));
+    }
+    SGO_HIP(hipGetLastError());
+    return SGO_OK;
+}
+int launch_score(int S, int n, const uint32_t *d_packed, const int32_t *d_idx, double komi, int32_t *d_result,
+                 hipStream_t st) {
+    if (n <= 0) return SGO_OK;
+    SGO_DISPATCH(S, k_score<kS><<<dim3(cdiv(n, 64)), dim3(64), 0, st>>>(n, d_packed, d_idx, komi, d_result));
+    SGO_HIP(hipGetLastError());
+    return SGO_OK;
+}
+
+// grow-only device scratch for the host-buffer entry points
+struct Scratch {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return SGO_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 2 + 4096;
+        SGO_HIP(hipMalloc(&p, want));
+        cap = want;
+        return SGO_OK;
+    }
+};
+static std::mutex g_mu;
+static Scratch g_s[4];
+
+template <int S>
+static constexpr int pack_threads() { return ((Geo<S>::N + 63) / 64) * 64; }
+
+}  // namespace sgo
+
+using namespace sgo;
+
+extern "C" {
+
+const char *sgo_last_error(void) { return g_err.c_str(); }
+int sgo_version(void) { return 1; }
+int sgo_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+int sgo_set_device(int d) {
+    SGO_HIP(hipSetDevice(d));
+    return SGO_OK;
+}
+
+int sgo_plane_words(int S) { return size_ok(S) ? (S * S + 31) / 32 : SGO_ERR_ARG; }
+int sgo_packed_words(int S) { return size_ok(S) ? ((16 * ((S * S + 31) / 32) + 1 + 3) / 4) * 4 : SGO_ERR_ARG; }
+int sgo_apad(int S) { return size_ok(S) ? 32 * ((S * S + 31) / 32) : SGO_ERR_ARG; }
+
+int sgo_sym_lut(int S, int k, int32_t *lut) {
+    if (!size_ok(S) || k < 0 || k > 7 || !lut) { set_error("sgo_sym_lut: bad argument"); return SGO_ERR_ARG; }
+    build_sym_lut(S, k, lut);
+    return SGO_OK;
+}
+
+// ---- device-pointer API
+int sgo_pack_dev(int S, int n, const int32_t *d_board17, uint32_t *d_packed, void *stream) {
+    if (n <= 0) return SGO_OK;
+    SGO_DISPATCH(S, k_pack<kS><<<dim3(n), dim3(pack_threads<kS>()), 0, (hipStream_t)stream>>>(n, d_board17, d_packed));
+    SGO_HIP(hipGetLastError());
+    return SGO_OK;
+}
+int sgo_unpack_dev(int S, int n, const uint32_t *d_packed, int32_t *d_board17, void *stream) {
+    if (n <= 0) return SGO_OK;
+    SGO_DISPATCH(S, k_unpack<kS><<<dim3(n), dim3(pack_threads<kS>()), 0, (hipStream_t)stream>>>(n, d_packed, d_board17));
+    SGO_HIP(hipGetLastError());
+    return SGO_OK;
+}
+int sgo_advance_legal_dev(int S, int n, const uint32_t *d_in, const int32_t *d_in_idx, const int32_t *d_moves,
+                          const int32_t *d_colors, uint32_t *d_out, const int32_t *d_out_idx, uint32_t *d_legal,
+                          int32_t *d_status, void *stream) {
+    if (!size_ok(S) || n < 0 || !d_in || !d_out || !d_moves) { set_error("sgo_advance_legal_dev: bad argument"); return SGO_ERR_ARG; }
+    return launch_advance_legal(S, n, d_in, d_in_idx, d_moves, d_colors, d_out, d_out_idx, d_legal, nullptr, d_status,
+                                (hipStream_t)stream);
+}
+int sgo_legal_dev(int S, int n, const uint32_t *d_packed, const int32_t *d_idx, uint32_t *d_legal, void *stream) {
+    if (n <= 0) return SGO_OK;
+    SGO_DISPATCH(S, k_legal<kS><<<dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream>>>(n, d_packed, d_idx, d_legal));
+    SGO_HIP(hipGetLastError());
+    return SGO_OK;
+}
+int sgo_score_dev(int S, int n, const uint32_t *d_packed, const int32_t *d_idx, double komi, int32_t *d_result,
+                  void *stream) {
+    if (!size_ok(S)) { set_error("sgo_score_dev: bad size"); return SGO_ERR_ARG; }
+    return launch_score(S, n, d_packed, d_idx, komi, d_result, (hipStream_t)stream);
+}
+int sgo_nn_pack_dev(int S, int n, const uint32_t *d_packed, const int32_t *d_idx, int k, int layout, int dtype,
+                    void *d_out, void *stream) {
+    if (!size_ok(S) || k < 0 || k > 7 || layout < 0 || layout > 1 || dtype < 0 || dtype > 1) {
+        set_error("sgo_nn_pack_dev: bad argument");
+        return SGO_ERR_ARG;
+    }
+    return launch_nn_pack(S, n, d_packed, d_idx, k, layout, dtype, d_out, (hipStream_t)stream);
+}
+
+// ---- host-buffer API (drop-in for play.py / symmetry.py)
+int sgo_game_init(int S, int n, int32_t *board17) {
+    if (!size_ok(S) || n < 0 || !board17) { set_error("sgo_game_init: bad argument"); return SGO_ERR_ARG; }
+    if (sgo_device_count() <= 0) { set_error("no HIP device"); return SGO_ERR_HIP; }
+    memset(board17, 0, sizeof(int32_t) * (size_t)n * S * S * 17);
+    for (size_t i = 0; i < (size_t)n * S * S; i++) board17[i * 17 + 16] = 1;
+    return SGO_OK;
+}
+
+int sgo_make_play(int S, int n, int32_t *board17, const int32_t *xs, const int32_t *ys, const int32_t *colors,
+                  int32_t *movers, int32_t *status) {
+    if (!size_ok(S) || n < 0 || !board17 || !xs || !ys) { set_error("sgo_make_play: bad argument"); return SGO_ERR_ARG; }
+    if (n == 0) return SGO_OK;
+    std::lock_guard<std::mutex> lk(g_mu);
+    const size_t bsz = sizeof(int32_t) * (size_t)n * S * S * 17;
+    const size_t psz = sizeof(uint32_t) * (size_t)n * sgo_packed_words(S);
+    int r;
+    if ((r = g_s[0].ensure(bsz))) return r;
+    if ((r = g_s[1].ensure(psz))) return r;
+    if ((r = g_s[2].ensure(sizeof(int32_t) * (size_t)n * 3))) return r;
+    std::vector<int32_t> mv(n), st(n), col(n);
+    std::vector<char> bad(n, 0);
+    for (int i = 0; i < n; i++) {
+        int x = xs[i], y = ys[i];
+        if (y == S) mv[i] = S * S;                                  // pass (play.py:232)
+        else if (x < 0 || x >= S || y < 0 || y >= S) { mv[i] = -1; bad[i] = 1; }
+        else mv[i] = y * S + x;
+        col[i] = colors ? colors[i] : 0;
+    }
+    int32_t *d_mv = (int32_t *)g_s[2].p, *d_col = d_mv + n, *d_st = d_mv + 2 * n;
+    SGO_HIP(hipMemcpy(g_s[0].p, board17, bsz, hipMemcpyHostToDevice));
+    SGO_HIP(hipMemcpy(d_mv, mv.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
+    SGO_HIP(hipMemcpy(d_col, col.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
+    if ((r = sgo_pack_dev(S, n, (const int32_t *)g_s[0].p, (uint32_t *)g_s[1].p, nullptr))) return r;
+    if ((r = launch_advance_legal(S, n, (const uint32_t *)g_s[1].p, nullptr, d_mv, d_col, (uint32_t *)g_s[1].p, nullptr,
+                                  nullptr, nullptr, d_st, nullptr)))
+        return r;
+    if ((r = sgo_unpack_dev(S, n, (const uint32_t *)g_s[1].p, (int32_t *)g_s[0].p, nullptr))) return r;
+    SGO_HIP(hipMemcpy(st.data(), d_st, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+    std::vector<int32_t> outb((size_t)n * S * S * 17);
+    SGO_HIP(hipMemcpy(outb.data(), g_s[0].p, bsz, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; i++) {
+        bool ok = st[i] == 1 || st[i] == -1;
+        if (ok) memcpy(board17 + (size_t)i * S * S * 17, outb.data() + (size_t)i * S * S * 17, sizeof(int32_t) * S * S * 17);
+        if (movers) movers[i] = ok ? st[i] : 0;
+        if (status) status[i] = ok ? SGO_OK : st[i];
+    }
+    return SGO_OK;
+}
+
+int sgo_legal_moves(int S, int n, const int32_t *board17, uint8_t *mask) {
+    if (!size_ok(S) || n < 0 || !board17 || !mask) { set_error("sgo_legal_moves: bad argument"); return SGO_ERR_ARG; }
+    if (n == 0) return SGO_OK;
+    std::lock_guard<std::mutex> lk(g_mu);
+    const int A = S * S + 1, NW = sgo_plane_words(S);
+    const size_t bsz = sizeof(int32_t) * (size_t)n * S * S * 17;
+    int r;
+    if ((r = g_s[0].ensure(bsz))) return r;
+    if ((r = g_s[1].ensure(sizeof(uint32_t) * (size_t)n * sgo_packed_words(S)))) return r;
+    if ((r = g_s[2].ensure(sizeof(uint32_t) * (size_t)n * NW))) return r;
+    if ((r = g_s[3].ensure((size_t)n * A))) return r;
+    SGO_HIP(hipMemcpy(g_s[0].p, board17, bsz, hipMemcpyHostToDevice));
+    if ((r = sgo_pack_dev(S, n, (const int32_t *)g_s[0].p, (uint32_t *)g_s[1].p, nullptr))) return r;
+    if ((r = sgo_legal_dev(S, n, (const uint32_t *)g_s[1].p, nullptr, (uint32_t *)g_s[2].p, nullptr))) return r;
+    k_legal_to_mask<<<dim3((n * A + 255) / 256), dim3(256), 0, nullptr>>>(A, NW, n, (const uint32_t *)g_s[2].p, (uint8_t *)g_s[3].p);
+    SGO_HIP(hipGetLastError());
+    SGO_HIP(hipMemcpy(mask, g_s[3].p, (size_t)n * A, hipMemcpyDeviceToHost));
+    return SGO_OK;
+}
+
+int sgo_get_winner(int S, int n, const int32_t *board17, double komi, int32_t *winner, int32_t *black, double *white) {
+    if (!size_ok(S) || n < 0 || !board17) { set_error("sgo_get_winner: bad argument"); return SGO_ERR_ARG; }
+    if (n == 0) return SGO_OK;
+    std::lock_guard<std::mutex> lk(g_mu);
+    const size_t bsz = sizeof(int32_t) * (size_t)n * S * S * 17;
+    int r;
+    if ((r = g_s[0].ensure(bsz))) return r;
+    if ((r = g_s[1].ensure(sizeof(uint32_t) * (size_t)n * sgo_packed_words(S)))) return r;
+    if ((r = g_s[2].ensure(sizeof(int32_t) * (size_t)n * 3))) return r;
+    SGO_HIP(hipMemcpy(g_s[0].p, board17, bsz, hipMemcpyHostToDevice));
+    if ((r = sgo_pack_dev(S, n, (const int32_t *)g_s[0].p, (uint32_t *)g_s[1].p, nullptr))) return r;
+    if ((r = launch_score(S, n, (const uint32_t *)g_s[1].p, nullptr, komi, (int32_t *)g_s[2].p, nullptr))) return r;
+    std::vector<int32_t> res((size_t)n * 3);
+    SGO_HIP(hipMemcpy(res.data(), g_s[2].p, sizeof(int32_t) * n * 3, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; i++) {
+        if (winner) winner[i] = res[3 * i];
+        if (black) black[i] = res[3 * i + 1];
+        if (white) white[i] = (double)res[3 * i + 2] + komi;
+    }
+    return SGO_OK;
+}
+
+int sgo_sym_apply(int S, int k, int n, const int32_t *in17, int32_t *out17) {
+    if (!size_ok(S) || k < 0 || k > 7 || n < 0 || !in17 || !out17) { set_error("sgo_sym_apply: bad argument"); return SGO_ERR_ARG; }
+    if (n == 0) return SGO_OK;
+    std::lock_guard<std::mutex> lk(g_mu);
+    const size_t bsz = sizeof(int32_t) * (size_t)n * S * S * 17;
+    int r;
+    if ((r = g_s[0].ensure(bsz))) return r;
+    if ((r = g_s[1].ensure(bsz))) return r;
+    SGO_HIP(hipMemcpy(g_s[0].p, in17, bsz, hipMemcpyHostToDevice));
+    k_sym_apply<<<dim3((n * S * S + 255) / 256), dim3(256), 0, nullptr>>>(S, k, n, (const int32_t *)g_s[0].p, (int32_t *)g_s[1].p);
+    SGO_HIP(hipGetLastError());
+    SGO_HIP(hipMemcpy(out17, g_s[1].p, bsz, hipMemcpyDeviceToHost));
+    return SGO_OK;
+}
+
+int sgo_sym_invert_policy(int S, int k, int n, const float *in, float *out) {
+    if (!size_ok(S) || k < 0 || k > 7 || n < 0 || !in || !out) { set_error("sgo_sym_invert_policy: bad argument"); return SGO_ERR_ARG; }
+    if (n == 0) return SGO_OK;
+    std::lock_guard<std::mutex> lk(g_mu);
+    const int A = S * S + 1;
+    const size_t psz = sizeof(float) * (size_t)n * A;
+    int r;
+    if ((r = g_s[0].ensure(psz))) return r;
+    if ((r = g_s[1].ensure(psz))) return r;
+    if ((r = g_s[2].ensure(sizeof(int32_t) * A))) return r;
+    std::vector<int32_t> lut(A);
+    build_sym_lut(S, k, lut.data());
+    SGO_HIP(hipMemcpy(g_s[2].p, lut.data(), sizeof(int32_t) * A, hipMemcpyHostToDevice));
+    SGO_HIP(hipMemcpy(g_s[0].p, in, psz, hipMemcpyHostToDevice));
+    k_sym_policy<<<dim3((n * A + 255) / 256), dim3(256), 0, nullptr>>>(A, n, (const int32_t *)g_s[2].p, (const float *)g_s[0].p, (float *)g_s[1].p);
+    SGO_HIP(hipGetLastError());
+    SGO_HIP(hipMemcpy(out, g_s[1].p, psz, hipMemcpyDeviceToHost));
+    return SGO_OK;
+}
+
+}  // extern "C"

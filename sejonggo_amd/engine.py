@@ -1,0 +1,329 @@
+"""Host driver of the MI355X self-play engine (libsgo_hip.so, include/sgo.h "self-play engine").
+
+`SelfPlayEngine` keeps `n_games` games resident on one GPU and advances all of them in lock-free
+steps: collect the positions that need a network evaluation -> one batched forward pass of the
+resident policy/value net -> `sgo_step` (back-propagation, virtual-loss PUCT selection, move choice,
+re-rooting, board_advance for the new leaves, all on the GPU).  It is what sits underneath the
+reference-shaped entry points in nomodel_self_play.py / selfplay_worker.py of this package, and it
+replaces, for many games at once, the reference's process zoo around one game
+(nomodel_self_play.py:142-271 play_game_async + simulation_workers.py Pool + predicting_queue_worker.py).
+
+The net is any object with the reference's model contract (model.py:57,80,90): `.name` and
+`.predict_on_batch(X[n,S,S,17]) -> [policy [n,S*S+1] (float32), value [n,1] (float32)]`, here on CUDA
+tensors.  PyTorch is plumbing (device memory, stream, the net itself); the tree and the rules are HIP.
+"""
+import ctypes as C
+import math
+import random as pyrandom
+
+import numpy as np
+
+from . import _lib
+from .conf import conf
+
+END_REASONS = {0: "PLAYED ALL MOVES", 1: "resign", 2: "BOTH_PASSED"}
+
+
+def unpack_positions(packed, size):
+    """packed uint32 [n, RW] -> the reference's board tensor int32 [n, S, S, 17] (host-side format
+    conversion for move records; the hot path never leaves the packed form)."""
+    packed = np.ascontiguousarray(packed, dtype=np.uint32)
+    n = packed.shape[0]
+    N = size * size
+    NW = (N + 31) // 32
+    planes = packed[:, :16 * NW].reshape(n, 16, NW)
+    bits = np.unpackbits(planes.view(np.uint8).reshape(n, 16, NW * 4), axis=2, bitorder="little")[:, :, :N]
+    boards = np.zeros((n, size, size, 17), dtype=np.int32)
+    boards[:, :, :, :16] = bits.transpose(0, 2, 1).reshape(n, size, size, 16)
+    to_play = np.where(packed[:, 16 * NW] & 1, -1, 1).astype(np.int32)
+    boards[:, :, :, 16] = to_play[:, None, None]
+    return boards
+
+
+class SelfPlayEngine(object):
+    def __init__(self, net, size=None, n_games=None, sims=None, energy=None, stop_exploration=None, num_moves=None,
+                 komi=None, self_play=True, dirichlet_alpha=None, dirichlet_epsilon=None, blocks_per_game=0,
+                 device=0, symmetry="random1", layout="nhwc", dtype="fp16", seed=0):
+        import torch
+        self.torch = torch
+        self.lib = _lib.require_gpu()
+        self.net = net
+        self.S = size or conf['SIZE']
+        self.A = self.S * self.S + 1
+        self.G = n_games or conf['GAMES_PER_GPU']
+        self.sims = conf['MCTS_SIMULATIONS'] if sims is None else sims
+        self.E = conf['ENERGY'] if energy is None else energy
+        self.stop_exploration = conf['STOP_EXPLORATION'] if stop_exploration is None else stop_exploration
+        self.num_moves = num_moves
+        self.max_moves = 2 * self.S * self.S if num_moves is None else num_moves
+        self.komi = conf['KOMI'] if komi is None else komi
+        self.alpha = conf['DIRICHLET_ALPHA'] if dirichlet_alpha is None else dirichlet_alpha
+        self.symmetry = symmetry
+        assert symmetry in ("identity", "random1", "avg8") or symmetry in range(8)  # int k: always that symmetry
+        self.layout = {"nhwc": 0, "nchw": 1}[layout]
+        self.dtype = {"fp16": 0, "fp32": 1}[dtype]
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        cfg = _lib.Config(size=self.S, n_games=self.G, sims=self.sims, energy=self.E,
+                          stop_exploration=self.stop_exploration, num_moves=-1 if num_moves is None else num_moves,
+                          blocks_per_game=blocks_per_game, self_play=1 if self_play else 0, komi=self.komi,
+                          dirichlet_epsilon=conf['DIRICHLET_EPSILON'] if dirichlet_epsilon is None else dirichlet_epsilon,
+                          device_id=device, reserved=0)
+        self.ctx = C.c_void_p(self.lib.sgo_ctx_create(C.byref(cfg)))
+        if not self.ctx:
+            raise _lib.SgoError("sgo_ctx_create failed: %s" % self.lib.sgo_last_error().decode())
+        self.RW = self.lib.sgo_packed_words(self.S)
+        self.rng = np.random.RandomState(seed)
+        self.pyrng = pyrandom.Random(seed)
+        max_eval = self.G * self.E
+        tdt = torch.float16 if self.dtype == 0 else torch.float32
+        shape = (max_eval, self.S, self.S, 17) if self.layout == 0 else (max_eval, 17, self.S, self.S)
+        self.nn_in = torch.zeros(shape, dtype=tdt, device=self.device)
+        self.status = _lib.Status()
+        self._policy = None
+        self._value = None
+        self._sym_k = 0
+        self._luts = None
+        self.records = {}          # slot -> list of move dicts of the game in progress
+        self.finished = []         # finished game_data dicts
+        self.game_ids = {}         # slot -> caller-supplied id
+        self.n_steps = 0
+        self.n_net_calls = 0
+        self.n_net_positions = 0
+        self._primed = False
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.sgo_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ game slots
+    def start_games(self, slots, noises=None, uniforms=None, resign=None, ids=None):
+        """(Re)start game slots.  Draws default to numpy's own generators (np.random.dirichlet /
+        random_sample -- the same distributions the reference draws from, play.py:401, and
+        nomodel_self_play.py:135 through np.random.choice); tests inject recorded draws instead."""
+        slots = np.ascontiguousarray(slots, dtype=np.int32)
+        n = len(slots)
+        if n == 0:
+            return
+        if noises is None:
+            noises = self.rng.dirichlet([self.alpha] * self.A, size=n)
+        noises = np.ascontiguousarray(noises, dtype=np.float64).reshape(n, self.A)
+        if uniforms is None:
+            uniforms = self.rng.random_sample((n, max(1, self.max_moves)))
+        uniforms = np.ascontiguousarray(uniforms, dtype=np.float64).reshape(n, -1)
+        res = None
+        if resign is not None:
+            res = np.array([np.nan if r is None else r for r in resign], dtype=np.float32)
+        _lib.check(self.lib.sgo_start_games(self.ctx, C.c_int(n), _lib.ptr(slots), _lib.ptr(noises), _lib.ptr(uniforms),
+                                            C.c_int(uniforms.shape[1]), _lib.ptr(res)), "sgo_start_games")
+        for i, s in enumerate(slots):
+            self.records[int(s)] = []
+            self.game_ids[int(s)] = None if ids is None else ids[i]
+
+    # ------------------------------------------------------------------ one engine step
+    def _lut(self, k):
+        torch = self.torch
+        if self._luts is None:
+            from .symmetry import sym_lut
+            self._luts = [torch.from_numpy(sym_lut(self.S, kk).astype(np.int64)).to(self.device) for kk in range(8)]
+        return self._luts[k]
+
+    def _forward(self, n, k):
+        torch = self.torch
+        _lib.check(self.lib.sgo_collect(self.ctx, C.c_int(k), C.c_int(self.layout), C.c_int(self.dtype),
+                                        _lib.ptr(self.nn_in), _lib.stream_ptr()), "sgo_collect")
+        x = self.nn_in[:n]
+        if self.layout == 1:
+            x = x.permute(0, 2, 3, 1)  # present the reference's NHWC view
+        p, v = self.net.predict_on_batch(x)
+        self.n_net_calls += 1
+        self.n_net_positions += n
+        return p.to(torch.float32), v.to(torch.float32).reshape(n)
+
+    def step(self):
+        """One engine step; returns the status struct."""
+        torch = self.torch
+        n = self.status.n_eval if self._primed else 0
+        if n > 0:
+            if self.symmetry == "avg8":
+                pol = None
+                val = None
+                for k in range(8):
+                    p, v = self._forward(n, k)
+                    p = p.index_select(1, self._lut(k))   # reverse_*: policy[:, SWAP]
+                    pol = p if pol is None else pol + p
+                    val = v if val is None else val + v
+                pol = (pol / 8.0).contiguous()
+                val = (val / 8.0).contiguous()
+                k_used = 0
+            else:
+                if self.symmetry == "identity":
+                    k_used = 0
+                elif self.symmetry == "random1":
+                    k_used = self.pyrng.randrange(7)  # choice(SYMMETRIES), symmetry.py:128
+                else:
+                    k_used = int(self.symmetry)
+                pol, val = self._forward(n, k_used)
+                pol = pol.contiguous()
+                val = val.contiguous()
+            self._policy, self._value = pol, val  # keep alive until the step has consumed them
+            pp, vp = _lib.ptr(pol), _lib.ptr(val)
+        else:
+            pp, vp, k_used = None, None, 0
+        _lib.check(self.lib.sgo_step(self.ctx, pp, vp, C.c_int(k_used), _lib.stream_ptr(), C.byref(self.status)),
+                   "sgo_step")
+        self._primed = True
+        self.n_steps += 1
+        if self.status.error:
+            raise _lib.SgoError("game slot %d failed with error %d (%s)" % (
+                self.status.error_game, self.status.error,
+                {-201: "tree-block pool exhausted: raise blocks_per_game", -202: "ran out of injected random draws",
+                 -203: "engine state error"}.get(self.status.error, "?")))
+        return self.status
+
+    # ------------------------------------------------------------------ records / results
+    def drain(self):
+        """Moves recorded since the last drain, appended to the per-slot game records."""
+        n = self.status.n_records
+        if n <= 0:
+            return 0
+        cap = 2 * self.G + 16
+        recs = np.zeros(cap, dtype=_lib.MOVE_RECORD_DTYPE)
+        packed = np.zeros((cap, self.RW), dtype=np.uint32)
+        policy = np.zeros((cap, self.A), dtype=np.float64)
+        n = _lib.check(self.lib.sgo_drain_records(self.ctx, C.c_int(cap), _lib.ptr(recs), _lib.ptr(packed), _lib.ptr(policy)),
+                       "sgo_drain_records")
+        self.status.n_records = 0
+        if n == 0:
+            return 0
+        boards = unpack_positions(packed[:n], self.S)
+        order = np.lexsort((recs["move_n"][:n], recs["game"][:n]))
+        for i in order:
+            r = recs[i]
+            a = int(r["action"])
+            y = a // self.S
+            x = a - self.S * y
+            self.records.setdefault(int(r["game"]), []).append({
+                'board': boards[i:i + 1].copy(), 'policy': policy[i].copy(), 'value': np.float32(r["value"]),
+                'move': (x, y), 'move_n': int(r["move_n"]), 'player': int(r["player"]),
+            })
+        return n
+
+    def results(self, slots=None):
+        slots = np.arange(self.G, dtype=np.int32) if slots is None else np.ascontiguousarray(slots, dtype=np.int32)
+        out = np.zeros(len(slots), dtype=_lib.GAME_RESULT_DTYPE)
+        _lib.check(self.lib.sgo_game_results(self.ctx, C.c_int(len(slots)), _lib.ptr(slots), _lib.ptr(out)), "sgo_game_results")
+        return out
+
+    def game_data(self, slot, result, model_name=None):
+        """The reference's game_data dict (nomodel_self_play.py:261-270) for a finished slot."""
+        name = model_name or getattr(self.net, "name", "model")
+        winner = int(result["winner"])
+        player_string = {1: "B", 0: "D", -1: "W"}
+        if int(result["end_reason"]) == 1:
+            winner_string = "%s+R" % player_string[int(result["last_player"])]
+        else:
+            winner_string = "%s+%s" % (player_string[winner], abs(int(result["black"]) - float(result["white"])))
+        return {
+            'moves': self.records.get(int(slot), []),
+            'modelB_name': name, 'modelW_name': name,
+            'winner': {1: 1, -1: 0, 0: None}[winner],
+            'winner_model': None if winner == 0 else name,
+            'result': winner_string,
+            'resign_model1': None, 'resign_model2': None,
+            'end_reason': END_REASONS[int(result["end_reason"])],
+            'black_points': int(result["black"]), 'white_points': float(result["white"]),
+            'slot': int(slot), 'id': self.game_ids.get(int(slot)),
+        }
+
+    def run(self, max_steps=None):
+        """Steps until no game is active; returns finished game_data dicts (slots are not restarted)."""
+        steps = 0
+        while True:
+            st = self.step()
+            if st.n_records >= self.G:
+                self.drain()
+            steps += 1
+            if st.n_active == 0 or (max_steps is not None and steps >= max_steps):
+                break
+        self.drain()
+        res = self.results()
+        out = []
+        for s in range(self.G):
+            if res[s]["done"] == 1:
+                out.append(self.game_data(s, res[s]))
+        return out
+
+    # ------------------------------------------------------------------ introspection (parity tests)
+    def root_table(self, slot):
+        A = self.A
+        N = np.zeros(A, np.int32); W = np.zeros(A, np.float32); Q = np.zeros(A, np.float32)
+        P = np.zeros(A, np.float64); EX = np.zeros(A, np.int8)
+        rc, rv = C.c_int32(0), C.c_float(0)
+        _lib.check(self.lib.sgo_root_table(self.ctx, C.c_int(slot), _lib.ptr(N), _lib.ptr(W), _lib.ptr(Q), _lib.ptr(P),
+                                           _lib.ptr(EX), C.byref(rc), C.byref(rv)), "sgo_root_table")
+        return {"N": N, "W": W, "Q": Q, "P": P, "EX": EX, "root_count": rc.value, "root_value": np.float32(rv.value)}
+
+    def tree_serialize(self, slot):
+        nn, ne = C.c_int64(0), C.c_int64(0)
+        sz = _lib.check(self.lib.sgo_tree_serialize(self.ctx, C.c_int(slot), None, C.c_int64(0), C.byref(nn), C.byref(ne)),
+                        "sgo_tree_serialize")
+        buf = np.zeros(max(1, sz), dtype=np.uint8)
+        _lib.check(self.lib.sgo_tree_serialize(self.ctx, C.c_int(slot), _lib.ptr(buf), C.c_int64(sz), C.byref(nn), C.byref(ne)),
+                   "sgo_tree_serialize")
+        return buf[:sz], nn.value, ne.value
+
+    def board(self, slot):
+        b = np.zeros((1, self.S, self.S, 17), dtype=np.int32)
+        _lib.check(self.lib.sgo_game_board(self.ctx, C.c_int(slot), _lib.ptr(b)), "sgo_game_board")
+        return b
+
+    def set_halt(self, slot, move_n):
+        _lib.check(self.lib.sgo_set_halt(self.ctx, C.c_int(slot), C.c_int(move_n)), "sgo_set_halt")
+
+    def advance_timing(self):
+        ms, n, p = C.c_double(0), C.c_int64(0), C.c_int64(0)
+        _lib.check(self.lib.sgo_advance_timing(self.ctx, C.byref(ms), C.byref(n), C.byref(p)), "sgo_advance_timing")
+        return ms.value, n.value, p.value
+
+
+def smoke_selfplay():
+    """Tiny end-to-end run on cuda:0: the rounding-free HashNet game must reproduce the oracle's game
+    move for move and tree for tree; then a random-init resnet plays a few moves for structural sanity."""
+    import hashlib
+    import torch
+    from oracle import oracle as ora
+    from .stub_nets import make_stub
+    from .net import PolicyValueNet
+    S, sims, E = 9, 48, 8
+    rng = np.random.RandomState(3)
+    noise = rng.dirichlet([0.03] * (S * S + 1), size=1)
+    uni = rng.random_sample((1, 2 * S * S))
+    stub = make_stub("hash", S)
+    eng = SelfPlayEngine(stub, size=S, n_games=1, sims=sims, energy=E, stop_exploration=6, num_moves=10, komi=5.5,
+                         symmetry="identity", dtype="fp16")
+    eng.start_games([0], noises=noise, uniforms=uni)
+    games = eng.run()
+    g = ora.Game(S, sims, E, 6, 10, uniforms=uni[0], noises=noise).run(stub)
+    assert len(games) == 1 and len(games[0]['moves']) == g.n_moves == 10
+    for i, mv in enumerate(games[0]['moves']):
+        m = g.move(i)
+        assert mv['move'][0] + S * mv['move'][1] == m['action'] or (mv['move'][1] == S and m['action'] == S * S)
+        assert np.array_equal(mv['board'], m['board']) and mv['policy'].tobytes() == m['policy'].tobytes()
+    ta, _, _ = eng.tree_serialize(0)
+    tb, _, _ = g.tree_serialize()
+    assert hashlib.sha1(ta.tobytes()).digest() == hashlib.sha1(tb.tobytes()).digest(), "tree mismatch vs oracle"
+    eng.close()
+    net = PolicyValueNet(S, n_blocks=2, channels=32, name="smoke").cuda().half().eval()
+    eng = SelfPlayEngine(net, size=S, n_games=8, sims=16, energy=8, stop_exploration=2, num_moves=3, symmetry="random1")
+    eng.start_games(np.arange(8))
+    games = eng.run()
+    assert len(games) == 8 and all(len(gd['moves']) == 3 for gd in games)
+    eng.close()

@@ -1,0 +1,126 @@
+"""Resident PyTorch-ROCm policy/value network with the reference's topology and tensor contract.
+
+Topology restated from model.py:55-95 (Keras): stem Conv3x3(17->256) with padding omitted => 'valid'
+(the tower runs on (S-2)x(S-2)), BN, ReLU; N_RESIDUAL_BLOCKS x [Conv3x3 same, BN, ReLU, Conv3x3 same, BN,
++skip, ReLU] (model.py:37-46); policy head Conv1x1(->2), BN, ReLU, Flatten (channels-last order),
+Dense(S*S+1, softmax) (:73-80); value head Conv1x1(->2), BN, ReLU, Flatten, Dense(256, relu),
+Dense(1, tanh) (:83-90).  Contract (model.py:57,80,90,92): `.name`, `.predict_on_batch(X[n,S,S,17])`
+-> [policy float32 [n,S*S+1], value float32 [n,1]].
+
+Inference form: `fused()` folds every BatchNorm into the preceding convolution and switches to
+channels_last + the requested dtype, so a forward pass is conv/GEMM (MFMA through MIOpen/hipBLASLt) +
+ReLU only.  Weights are random-init unless loaded; there is no network access for checkpoints.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class ResidualBlock(nn.Module):
+    def __init__(self, ch):
+        super().__init__()
+        self.conv1 = nn.Conv2d(ch, ch, 3, padding=1)
+        self.bn1 = nn.BatchNorm2d(ch, eps=1e-3, momentum=0.01)  # Keras BatchNormalization defaults
+        self.conv2 = nn.Conv2d(ch, ch, 3, padding=1)
+        self.bn2 = nn.BatchNorm2d(ch, eps=1e-3, momentum=0.01)
+
+    def forward(self, x):
+        y = F.relu(self.bn1(self.conv1(x)))
+        y = self.bn2(self.conv2(y))
+        return F.relu(y + x)
+
+
+class PolicyValueNet(nn.Module):
+    def __init__(self, size=19, n_blocks=20, channels=256, name="model_0", stem_padding=0):
+        super().__init__()
+        self.size = size
+        self.name = name
+        self.A = size * size + 1
+        t = size - 2 + 2 * stem_padding  # tower side length ('valid' stem in the reference)
+        self.tower_side = t
+        self.stem = nn.Conv2d(17, channels, 3, padding=stem_padding)
+        self.stem_bn = nn.BatchNorm2d(channels, eps=1e-3, momentum=0.01)
+        self.blocks = nn.ModuleList([ResidualBlock(channels) for _ in range(n_blocks)])
+        self.p_conv = nn.Conv2d(channels, 2, 1)
+        self.p_bn = nn.BatchNorm2d(2, eps=1e-3, momentum=0.01)
+        self.p_fc = nn.Linear(2 * t * t, self.A)
+        self.v_conv = nn.Conv2d(channels, 2, 1)
+        self.v_bn = nn.BatchNorm2d(2, eps=1e-3, momentum=0.01)
+        self.v_fc1 = nn.Linear(2 * t * t, 256)
+        self.v_fc2 = nn.Linear(256, 1)
+        self._fused = False
+
+    # ---- training-form forward on NCHW input
+    def forward(self, x):
+        y = self.stem(x)
+        y = F.relu(y if self._fused else self.stem_bn(y))
+        for b in self.blocks:
+            if self._fused:
+                z = F.relu(b.conv1(y))
+                y = F.relu(b.conv2(z) + y)
+            else:
+                y = b(y)
+        p = self.p_conv(y)
+        p = F.relu(p if self._fused else self.p_bn(p))
+        p = p.permute(0, 2, 3, 1).reshape(p.shape[0], -1)   # Keras flattens channels-last
+        p = torch.softmax(self.p_fc(p).float(), dim=1)
+        v = self.v_conv(y)
+        v = F.relu(v if self._fused else self.v_bn(v))
+        v = v.permute(0, 2, 3, 1).reshape(v.shape[0], -1)
+        v = torch.tanh(self.v_fc2(F.relu(self.v_fc1(v))).float())
+        return p, v
+
+    @torch.no_grad()
+    def predict_on_batch(self, X):
+        """X: [n,S,S,17] (NHWC like the reference), numpy or torch, any real dtype."""
+        dev = next(self.parameters()).device
+        dt = next(self.parameters()).dtype
+        if not torch.is_tensor(X):
+            import numpy as np
+            X = torch.from_numpy(np.ascontiguousarray(X))
+        x = X.to(device=dev, dtype=dt).permute(0, 3, 1, 2)   # NCHW view; stays channels_last in memory
+        p, v = self.forward(x)
+        return p, v
+
+    @torch.no_grad()
+    def fused(self, dtype=torch.float16):
+        """Inference copy: BN folded into the convolutions, channels_last, `dtype`."""
+        import copy
+        m = copy.deepcopy(self).float().eval()
+
+        def fold(conv, bn):
+            s = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+            conv.weight.mul_(s.reshape(-1, 1, 1, 1))
+            conv.bias.copy_((conv.bias - bn.running_mean) * s + bn.bias)
+
+        fold(m.stem, m.stem_bn)
+        for b in m.blocks:
+            fold(b.conv1, b.bn1)
+            fold(b.conv2, b.bn2)
+        fold(m.p_conv, m.p_bn)
+        fold(m.v_conv, m.v_bn)
+        m._fused = True
+        m = m.to(dtype).to(memory_format=torch.channels_last)
+        return m
+
+    def flops_per_eval(self):
+        """Forward FLOPs (MAC = 2) of one position, as SURVEY.md §8d counts them."""
+        t2 = self.tower_side ** 2
+        ch = self.stem.out_channels
+        f = 2 * t2 * 9 * 17 * ch
+        f += len(self.blocks) * 2 * 2 * t2 * 9 * ch * ch
+        f += 2 * 2 * t2 * ch * 2
+        f += 2 * (2 * t2) * self.A + 2 * (2 * t2) * 256 + 2 * 256
+        return f
+
+
+def build_net(size, n_blocks, channels=256, name="model_0", seed=0, device="cuda", dtype=torch.float16):
+    torch.manual_seed(seed)
+    net = PolicyValueNet(size, n_blocks, channels, name=name)
+    # non-trivial BN statistics so that folding is exercised
+    for mod in net.modules():
+        if isinstance(mod, nn.BatchNorm2d):
+            mod.running_mean.normal_(0, 0.1)
+            mod.running_var.uniform_(0.5, 1.5)
+    net.eval()
+    return net.fused(dtype).to(device)

@@ -1,0 +1,202 @@
+"""GPU parity tests of the self-play engine (k_search / k_compact / board_advance through sgo_step):
+every golden game recorded from the Python reference must be reproduced move for move, with bit-identical
+root tables, whole-tree hashes, policy targets and results; many concurrent games must each equal the
+oracle's game; symmetry handling (fixed k, 8-fold average) must equal the oracle driven through the same
+transforms."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from tests.helpers import load, sha8, ASYNC_FILES
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    from sejonggo_amd import _lib
+    _lib.require_gpu()
+    return _lib
+
+
+def _engine(z, net, halt_at=None, **kw):
+    from sejonggo_amd.engine import SelfPlayEngine
+    S = int(z["size"])
+    nm = int(z["num_moves"])
+    eng = SelfPlayEngine(net, size=S, n_games=1, sims=int(z["sims"]), energy=int(z["energy"]),
+                         stop_exploration=int(z["stop_exploration"]), num_moves=None if nm < 0 else nm,
+                         komi=float(z["komi"]), symmetry="identity", **kw)
+    uni = np.zeros((1, max(1, eng.max_moves)))
+    uni[0, :len(z["uniforms"])] = z["uniforms"]
+    eng.start_games([0], noises=z["noises"][:1], uniforms=uni)
+    if halt_at is not None:
+        eng.set_halt(0, halt_at)
+    return eng
+
+
+@pytest.mark.parametrize("fn", ASYNC_FILES)
+def test_golden_games(L, fn):
+    from sejonggo_amd.stub_nets import make_stub
+    z = load(fn)
+    S = int(z["size"])
+    net = make_stub(bytes(z["net"]).decode(), S)
+    eng = _engine(z, net)
+    games = eng.run()
+    assert len(games) == 1
+    gd = games[0]
+    n_moves = len(z["move_index"])
+    assert len(gd["moves"]) == n_moves
+    for i, mv in enumerate(gd["moves"]):
+        a = mv["move"][0] + S * mv["move"][1] if mv["move"][1] != S else S * S
+        assert a == z["move_index"][i], i
+        assert tuple(mv["move"]) == tuple(z["move_xy"][i]), i
+        assert mv["player"] == z["move_player"][i], i
+        assert mv["move_n"] == i
+        assert mv["value"].tobytes() == z["move_value"][i].tobytes(), i
+        assert mv["board"].dtype == np.int32 and np.array_equal(sha8(mv["board"]), z["move_board_hash"][i]), i
+        assert mv["policy"].dtype == np.float64 and mv["policy"].tobytes() == z["move_policy"][i].tobytes(), i
+    assert gd["result"] == bytes(z["result"]).decode()
+    assert (-99 if gd["winner"] is None else gd["winner"]) == int(z["winner"])
+    st = eng.status
+    assert st.total_evals == int(z["n_predict"])
+    assert st.none_events == int(z["none_events"])
+    assert st.total_moves == n_moves
+    eng.close()
+
+
+@pytest.mark.parametrize("fn", ASYNC_FILES)
+def test_golden_trees(L, fn):
+    """Root child tables and the canonical whole-tree hash right after the search of selected moves."""
+    from sejonggo_amd.stub_nets import make_stub
+    z = load(fn)
+    S = int(z["size"])
+    net = make_stub(bytes(z["net"]).decode(), S)
+    n_moves = len(z["move_index"])
+    for k in sorted(set([0, 1, min(3, n_moves - 1), n_moves // 2, n_moves - 1])):
+        eng = _engine(z, net, halt_at=k)
+        eng.run()
+        t = eng.root_table(0)
+        assert np.array_equal(t["N"], z["pm_N"][k]), k
+        assert t["W"].tobytes() == z["pm_W"][k].tobytes(), k
+        assert t["Q"].tobytes() == z["pm_Q"][k].tobytes(), k
+        assert t["P"].tobytes() == z["pm_P"][k].tobytes(), k
+        assert np.array_equal(t["EX"], z["pm_EX"][k]), k
+        assert t["root_count"] == z["pm_root_count"][k], k
+        assert t["root_value"].tobytes() == z["pm_root_value"][k].tobytes(), k
+        buf, nn, ne = eng.tree_serialize(0)
+        assert nn == z["pm_n_nodes"][k] and ne == z["pm_n_expanded"][k], k
+        assert hashlib.sha1(buf.tobytes()).digest()[:16] == z["pm_tree_hash"][k].tobytes(), k
+        eng.close()
+
+
+def test_many_concurrent_games_equal_the_oracle(L):
+    """64 games with different draws share one GPU context; each must equal the oracle's game."""
+    from oracle import oracle as ora
+    from sejonggo_amd.engine import SelfPlayEngine
+    from sejonggo_amd.stub_nets import make_stub
+    S, sims, E, G, nm = 9, 48, 8, 64, 14
+    net = make_stub("hash", S)
+    rng = np.random.RandomState(11)
+    noises = rng.dirichlet([0.03] * (S * S + 1), size=G)
+    uni = rng.random_sample((G, nm))
+    eng = SelfPlayEngine(net, size=S, n_games=G, sims=sims, energy=E, stop_exploration=5, num_moves=nm, komi=5.5,
+                         symmetry="identity")
+    eng.start_games(np.arange(G), noises=noises, uniforms=uni)
+    games = eng.run()
+    assert len(games) == G
+    for gd in games:
+        s = gd["slot"]
+        g = ora.Game(S, sims, E, 5, nm, uniforms=uni[s], noises=noises[s:s + 1]).run(net)
+        assert g.n_moves == len(gd["moves"])
+        for i, mv in enumerate(gd["moves"]):
+            m = g.move(i)
+            assert np.array_equal(mv["board"], m["board"]) and mv["policy"].tobytes() == m["policy"].tobytes(), (s, i)
+            assert mv["player"] == m["player"] and mv["value"].tobytes() == m["value"].tobytes()
+        r = g.result()
+        assert {1: 1, -1: 0, 0: None}[r["winner"]] == gd["winner"]
+        ta, _, _ = eng.tree_serialize(s)
+        tb, _, _ = g.tree_serialize()
+        assert ta.tobytes() == tb.tobytes(), s
+    eng.close()
+
+
+class _SymNet(object):
+    """Oracle-side wrapper: evaluates the stub through symmetry k exactly like random_symmetry_predict
+    (symmetry.py:127-132), or the 8-fold average (build extension)."""
+
+    def __init__(self, net, S, ks):
+        self.net, self.S, self.ks, self.name = net, S, ks, net.name
+
+    def predict_on_batch(self, boards):
+        from oracle import oracle as ora
+        pol, val = None, None
+        for k in self.ks:
+            p, v = self.net.predict_on_batch(ora.sym_board(k, boards))
+            p = ora.sym_policy_inverse(self.S, k, p)
+            pol = p if pol is None else pol + p
+            val = v if val is None else val + v
+        if len(self.ks) > 1:
+            pol = pol / np.float32(len(self.ks))
+            val = val / np.float32(len(self.ks))
+        return pol, val
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3, 4, 5, 6, 7, "avg8"])
+def test_symmetry_modes_equal_the_oracle(L, mode):
+    from oracle import oracle as ora
+    from sejonggo_amd.engine import SelfPlayEngine
+    from sejonggo_amd.stub_nets import make_stub
+    S, sims, E, nm = 9, 32, 8, 6
+    net = make_stub("hash", S)
+    rng = np.random.RandomState(21)
+    noises = rng.dirichlet([0.03] * (S * S + 1), size=2)
+    uni = rng.random_sample((2, nm))
+    eng = SelfPlayEngine(net, size=S, n_games=2, sims=sims, energy=E, stop_exploration=3, num_moves=nm, komi=5.5,
+                         symmetry=mode)
+    eng.start_games([0, 1], noises=noises, uniforms=uni)
+    games = eng.run()
+    ks = list(range(8)) if mode == "avg8" else [mode]
+    for gd in games:
+        s = gd["slot"]
+        g = ora.Game(S, sims, E, 3, nm, uniforms=uni[s], noises=noises[s:s + 1]).run(_SymNet(net, S, ks))
+        assert [m["move"][0] + S * m["move"][1] if m["move"][1] != S else S * S for m in gd["moves"]] == \
+               [g.move(i)["action"] for i in range(g.n_moves)]
+        ta, _, _ = eng.tree_serialize(s)
+        tb, _, _ = g.tree_serialize()
+        assert ta.tobytes() == tb.tobytes()
+    eng.close()
+
+
+def test_real_net_selfplay_runs_and_restarts(L):
+    """Random-init fp16 resnet: games finish, slots restart, records are well-formed."""
+    import torch
+    from sejonggo_amd.engine import SelfPlayEngine
+    from sejonggo_amd.net import build_net
+    S = 9
+    net = build_net(S, 2, 64, name="tiny")
+    eng = SelfPlayEngine(net, size=S, n_games=32, sims=16, energy=8, stop_exploration=4, num_moves=12, symmetry="random1")
+    eng.start_games(np.arange(32))
+    games = eng.run()
+    assert len(games) == 32
+    for gd in games:
+        assert 1 <= len(gd["moves"]) <= 12
+        for mv in gd["moves"]:
+            assert mv["board"].shape == (1, S, S, 17) and abs(float(mv["value"])) <= 1.0
+            assert mv["policy"].shape == (S * S + 1,) and mv["policy"].min() >= 0
+    eng.start_games(np.arange(8))      # restart some slots
+    games2 = eng.run()
+    assert len(games2) == 32
+    eng.close()
+
+
+def test_capacity_error_is_loud(L):
+    from sejonggo_amd import _lib
+    from sejonggo_amd.engine import SelfPlayEngine
+    from sejonggo_amd.stub_nets import make_stub
+    eng = SelfPlayEngine(make_stub("hash", 9), size=9, n_games=1, sims=64, energy=8, stop_exploration=0, num_moves=4,
+                         blocks_per_game=20, symmetry="identity")
+    eng.start_games([0])
+    with pytest.raises(_lib.SgoError):
+        eng.run()
+    eng.close()
