@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""Headline benchmark: self-play positions/sec (19x19, 400 sims/move) on N MI355X.
+
+Contract (one JSON line on rank 0): see the task statement.  A "step" = every resident game advances
+by ONE move: 1 root evaluation + sims/energy search rounds of `energy` leaves each, i.e. (1 + 400)
+network evaluations, 400 board_advance leaf positions and one move record per game.
+  value     = n_gpus * games_per_gpu * steps / seconds   (whole job, positions/sec)
+  roofline  = the board_advance kernel (k_leaf_advance): algorithmic bytes per launch (1834 B per leaf at
+              19x19) / its average duration, HIP events on the launch stream inside sgo_step
+  cpu_baseline = the oracle (C restatement of the reference's rules + tree) driving the same net on torch
+              CPU fp32, on a bounded sample, host cores stated ("kind": "port")
+Multi-GPU: one process per GPU, games sharded statically, no collective in the search; the per-step move
+records are gathered to rank 0 over RCCL inside the timed region (weak scaling).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES = {19: 1834, 13: 6 * 4 * 16 * 2 + 8 * 2 + 170, 9: 434, 7: 0, 5: 0}  # SURVEY.md §8d per leaf advance
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=19)
+    ap.add_argument("--sims", type=int, default=400)
+    ap.add_argument("--energy", type=int, default=8)
+    ap.add_argument("--games", type=int, default=1024, help="concurrent games per GPU")
+    ap.add_argument("--blocks", type=int, default=20)
+    ap.add_argument("--channels", type=int, default=256)
+    ap.add_argument("--symmetry", default="random1", choices=["random1", "avg8", "identity"])
+    ap.add_argument("--net", default="resnet", choices=["resnet", "uniform", "hash"])
+    ap.add_argument("--cpu-baseline", type=int, default=1)
+    ap.add_argument("--cpu-games", type=int, default=2)
+    ap.add_argument("--cpu-moves", type=int, default=1)
+    return ap.parse_args()
+
+
+def cpu_baseline(args, size, sims, energy, n_blocks, channels, symmetry):
+    """Oracle (port) + the same net on torch CPU fp32; bounded sample; returns dict."""
+    import numpy as np
+    import torch
+    from oracle import oracle as ora
+    from sejonggo_amd.net import PolicyValueNet
+    from sejonggo_amd.stub_nets import make_stub
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    if args.net == "resnet":
+        torch.manual_seed(0)
+        net = PolicyValueNet(size, n_blocks, channels, name="cpu").eval().fused(torch.float32)
+        net = net.to(memory_format=torch.channels_last)
+    else:
+        net = make_stub(args.net, size)
+    ng, nm = args.cpu_games, args.cpu_moves
+    rng = np.random.RandomState(0)
+    games = [ora.Game(size, sims, energy, 30, nm, uniforms=rng.random_sample(nm + 1),
+                      noises=rng.dirichlet([0.03] * (size * size + 1), size=1)) for _ in range(ng)]
+    ks = list(range(8)) if symmetry == "avg8" else [0]
+    t0 = time.time()
+    evals = 0
+    while any(g.phase != ora.PH_DONE for g in games):
+        pend = [(g, g.pending().copy()) for g in games if g.phase != ora.PH_DONE]
+        boards = np.concatenate([b for _, b in pend])
+        pol, val = None, None
+        for k in ks:
+            xb = ora.sym_board(k, boards) if k else boards
+            p, v = net.predict_on_batch(xb.astype(np.float32))
+            p = p.numpy() if torch.is_tensor(p) else p
+            v = v.numpy() if torch.is_tensor(v) else v
+            if k:
+                p = ora.sym_policy_inverse(size, k, p)
+            pol = p if pol is None else pol + p
+            val = v if val is None else val + v
+        pol = (pol / len(ks)).astype(np.float32)
+        val = (val / len(ks)).astype(np.float32)
+        evals += len(boards)
+        o = 0
+        for g, b in pend:
+            g.submit(pol[o:o + len(b)], val[o:o + len(b)])
+            o += len(b)
+    dt = time.time() - t0
+    positions = sum(g.n_moves for g in games)
+    return {"value": positions / dt, "unit": "positions/sec", "cores": cores, "kind": "port",
+            "sample": "%d concurrent games x %d move(s) (%d net evals), oracle C rules+tree (1 thread) + torch CPU fp32 "
+                      "net on %d threads, %.1f s" % (ng, nm, evals, cores, dt)}
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+        local = 0
+    from sejonggo_amd.engine import SelfPlayEngine
+    from sejonggo_amd.net import build_net
+    from sejonggo_amd.stub_nets import make_stub
+    from sejonggo_amd.distributed import tuple_dtype, gather_tuples
+    S, G, sims, E = args.size, args.games, args.sims, args.energy
+    if args.net == "resnet":
+        net = build_net(S, args.blocks, args.channels, name="bench_%db" % args.blocks, seed=0, device="cuda")
+    else:
+        net = make_stub(args.net, S)
+    eng = SelfPlayEngine(net, size=S, n_games=G, sims=sims, energy=E, stop_exploration=30, symmetry=args.symmetry,
+                         device=local, seed=1234 + rank)
+    eng.start_games(np.arange(G))
+    tdt = tuple_dtype(S)
+
+    def one_step():
+        """every game advances one move; then this step's records are gathered to rank 0"""
+        target = eng.status.total_moves + G
+        while eng.status.total_moves < target:
+            st = eng.step()
+            if st.n_active < G:
+                raise RuntimeError("a game ended inside the benchmark window")
+        n = eng.drain()
+        recs = np.zeros(n, dtype=tdt)
+        k = 0
+        for s in range(G):
+            for mv in eng.records[s]:
+                recs[k]["rank"] = rank; recs[k]["game"] = s; recs[k]["move_n"] = mv["move_n"]
+                recs[k]["player"] = mv["player"]; recs[k]["value"] = mv["value"]; recs[k]["z"] = np.nan
+                recs[k]["pi"] = mv["policy"]; recs[k]["state"] = mv["packed"]; recs[k]["action"] = mv["action"]
+                recs[k]["game_seq"] = mv["game_seq"]
+                k += 1
+            eng.records[s] = []
+        return gather_tuples(recs[:k])
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    eng.advance_timing()
+    evals0 = eng.status.total_evals
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    sync()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    adv_ms, adv_n, adv_pos = eng.advance_timing()
+    evals = eng.status.total_evals - evals0
+    out = None
+    if rank == 0:
+        positions = world * G * args.steps
+        per_launch = adv_pos / max(adv_n, 1)
+        avg_ms = adv_ms / max(adv_n, 1)
+        algo = ALGO_BYTES.get(S, 0) * per_launch
+        achieved = algo / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        flops = net.flops_per_eval() if hasattr(net, "flops_per_eval") else 0
+        sym_mult = 8 if args.symmetry == "avg8" else 1
+        out = {
+            "metric": "self-play positions/sec (19x19, 400 sims/move)" if (S, sims) == (19, 400) else
+                      "self-play positions/sec (%dx%d, %d sims/move)" % (S, S, sims),
+            "value": positions / dt, "unit": "positions/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u32 bitboards + f32 tree statistics (net: fp16)",
+            "data": "synthetic: self-generated positions from the empty board, random-init weights",
+            "config": {"workload": "%dx%d board, %d sims/move (energy %d), %d concurrent games per GPU, %s, symmetry=%s"
+                                   % (S, S, sims, E, G, ("random-init %d-block/%d-filter resnet fp16" % (args.blocks, args.channels))
+                                      if args.net == "resnet" else args.net + " stub net", args.symmetry),
+                       "games_per_gpu": G, "sims": sims, "energy": E, "net_evals_per_position": (sims // E) * E + 1,
+                       "sharding": "games g -> rank g mod N; RCCL gather of per-step records to rank 0"},
+            "roofline": {"bound": "hbm", "kernel": "k_leaf_advance (board_advance: make_play + legal set)",
+                         "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                         "traffic": None, "algorithmic_bytes_per_position": ALGO_BYTES.get(S, 0),
+                         "positions_per_launch": per_launch, "avg_launch_ms": avg_ms, "launches": adv_n},
+            "net": {"evals": int(evals), "flops_per_eval": flops,
+                    "achieved_tflops": (evals * sym_mult * flops / dt / 1e12) if flops else None,
+                    "peak_tflops": 2500.0, "bound": "mfma"},
+        }
+        if args.cpu_baseline and world == 1:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args, S, sims, E, args.blocks, args.channels, args.symmetry)
+            except Exception as ex:  # the GPU number stands on its own; say why the comparator is missing
+                out["cpu_baseline"] = {"value": None, "error": repr(ex)}
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -68,6 +68,10 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise SgoError("libsgo_hip.so is not built (run `python -m sejonggo_amd.build` or __graft_entry__.build()); "
                        "the MI355X path has no CPU fallback")
+    # PyTorch-ROCm wheels bundle their own libamdhip64.so.7; two HIP runtimes in one process cannot both
+    # own the GPU.  Importing torch first makes the dynamic linker resolve our NEEDED libamdhip64.so.7 to
+    # the copy torch already loaded, so the engine and the net share one runtime (streams, pointers).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     lib.sgo_last_error.restype = C.c_char_p
     lib.sgo_ctx_create.restype = C.c_void_p

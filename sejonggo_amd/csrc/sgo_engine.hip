@@ -788,7 +788,7 @@ sgo_ctx *sgo_ctx_create(const sgo_config *cfg) {
     c.cfg = *cfg;
     c.S = cfg->size; c.A = c.S * c.S + 1; c.NW = sgo_plane_words(c.S); c.RW = sgo_packed_words(c.S);
     c.APAD = 32 * c.NW; c.G = cfg->n_games; c.E = cfg->energy;
-    c.cap = cfg->blocks_per_game > 0 ? cfg->blocks_per_game : 3 * cfg->sims + 64;
+    c.cap = cfg->blocks_per_game > 0 ? cfg->blocks_per_game : 10 * cfg->sims + 64;
     if (c.cap < cfg->energy + 2) c.cap = cfg->energy + 2;
     c.max_moves = cfg->num_moves < 0 ? 2 * c.S * c.S : cfg->num_moves;
     c.rec_cap = 2 * c.G + 16;

@@ -213,6 +213,7 @@ class SelfPlayEngine(object):
             self.records.setdefault(int(r["game"]), []).append({
                 'board': boards[i:i + 1].copy(), 'policy': policy[i].copy(), 'value': np.float32(r["value"]),
                 'move': (x, y), 'move_n': int(r["move_n"]), 'player': int(r["player"]),
+                'packed': packed[i].copy(), 'action': a, 'game_seq': int(r["game_seq"]),
             })
         return n
 

@@ -1,0 +1,164 @@
+"""Drop-in for the reference's selfplay_worker.py: NoModelSelfPlayWorker(process_id) and
+SelfPlayWorker(gpuid, forever=False, one_game_only=-1) are multiprocessing.Process subclasses with the
+reference's start()/join() life cycle, game-directory reservation (selfplay_worker.py:83-90), resign-
+threshold calibration (:92-112) and zero-move clean-up (:115-118).
+
+Difference in kind, not in contract: the reference runs ONE game per process (and 8 pool workers under it);
+here one process drives ONE MI355X that keeps conf['GAMES_PER_GPU'] games resident, reserving the next free
+game directory whenever a slot finishes.  Run one worker per GPU (conf['N_GAME_PROCESS'] = number of GPUs)."""
+import os
+import sys
+import traceback
+from multiprocessing import Process
+from random import random
+
+import numpy as np
+
+from .conf import conf
+
+
+class GameScheduler(object):
+    """Host logic shared by both workers: which game number a free slot plays next, and the resign
+    threshold (selfplay_worker.py:82-112).  Pure bookkeeping; no compute."""
+
+    def __init__(self, self_play_dir, model_name, n_games, resignation_percent, allowed_error, rand=random):
+        self.dir, self.model_name, self.n_games = self_play_dir, model_name, n_games
+        self.resignation_percent, self.allowed_error = resignation_percent, allowed_error
+        self.rand = rand
+        self.next_game = 0
+        self.current_resign = None
+        self.min_values = []
+
+    def reserve(self):
+        """Next game number whose directory could be created, or None when range(n_games) is exhausted."""
+        while self.next_game < self.n_games:
+            g = self.next_game
+            self.next_game += 1
+            directory = os.path.join(self.dir, self.model_name, "game_%05d" % g)
+            if os.path.isdir(directory):
+                continue
+            try:
+                os.makedirs(directory)
+            except Exception:
+                continue
+            return g
+        return None
+
+    def pick_resign(self):
+        return self.current_resign if self.rand() > self.resignation_percent else None
+
+    def finished(self, game_data, resign):
+        """selfplay_worker.py:100-112: only no-resign games calibrate the threshold; the list is kept in
+        arrival order (not sorted), as the reference does."""
+        if resign is None and game_data['moves']:
+            winner = game_data['winner']
+            vals = [m['value'] for m in game_data['moves'][::2]] if winner == 1 else [m['value'] for m in game_data['moves'][1::2]]
+            if vals:
+                self.min_values.append(min(vals))
+                idx = int(self.allowed_error * len(self.min_values))
+                if idx > 0:
+                    self.current_resign = self.min_values[idx]
+
+    def discard(self, game_no):
+        try:
+            os.rmdir(os.path.join(self.dir, self.model_name, "game_%05d" % game_no))
+        except OSError:
+            pass
+
+
+def run_selfplay(gpu_id, model_indicator="BEST_SYM", n_games=None, games_per_gpu=None, on_game=None, max_steps=None):
+    """The worker body, callable in-process (tests, bench) as well as from the Process subclasses."""
+    from .engine import SelfPlayEngine
+    from .predicting_queue_worker import init_predicting_workers, get_model, put_name_request
+    from .sgfsave import save_self_play_data
+    init_predicting_workers([gpu_id])
+    net = get_model(model_indicator, gpu_id)
+    model_name = put_name_request(model_indicator)
+    n_games = conf['N_GAMES'] if n_games is None else n_games
+    G = min(games_per_gpu or conf['GAMES_PER_GPU'], max(1, n_games))
+    sched = GameScheduler(conf['SELF_PLAY_DIR'], model_name, n_games, conf['RESIGNATION_PERCENT'],
+                          conf['RESIGNATION_ALLOWED_ERROR'])
+    sym = conf.get('SYMMETRY_MODE', 'random1') if model_indicator.endswith("_SYM") else "identity"
+    eng = SelfPlayEngine(net, size=conf['SIZE'], n_games=G, sims=conf['MCTS_SIMULATIONS'], energy=conf['ENERGY'],
+                         stop_exploration=conf['STOP_EXPLORATION'], komi=conf['KOMI'], self_play=True, symmetry=sym,
+                         device=gpu_id, seed=gpu_id)
+    slot_game, slot_resign = {}, {}
+
+    def fill(slots):
+        start, res, ids = [], [], []
+        for s in slots:
+            g = sched.reserve()
+            if g is None:
+                continue
+            r = sched.pick_resign()
+            slot_game[s], slot_resign[s] = g, r
+            start.append(s); res.append(r); ids.append(g)
+        if start:
+            eng.start_games(start, resign=res, ids=ids)
+        return len(start)
+
+    played = 0
+    try:
+        active = fill(range(G))
+        steps = 0
+        while active > 0:
+            st = eng.step()
+            steps += 1
+            if st.n_records >= G:
+                eng.drain()
+            if st.n_done > 0:
+                eng.drain()
+                res = eng.results()
+                free = []
+                for s in list(slot_game):
+                    if res[s]["done"] != 1:
+                        continue
+                    gd = eng.game_data(s, res[s], model_name)
+                    gd['resign_model1'] = gd['resign_model2'] = slot_resign[s]
+                    g = slot_game.pop(s)
+                    sched.finished(gd, slot_resign.pop(s))
+                    if len(gd['moves']) == 0:
+                        sched.discard(g)
+                    else:
+                        save_self_play_data(model_name, g, gd)
+                        played += 1
+                        if on_game is not None:
+                            on_game(g, gd)
+                    free.append(s)
+                    active -= 1
+                active += fill(free)
+            if max_steps is not None and steps >= max_steps:
+                break
+    finally:
+        eng.close()
+    return played
+
+
+class NoModelSelfPlayWorker(Process):
+    def __init__(self, process_id):
+        Process.__init__(self, name='SelfPlayProcessor')
+        self._process_id = process_id
+
+    def run(self):
+        try:
+            gpus = conf['GPUs']
+            run_selfplay(gpus[self._process_id % len(gpus)], "BEST_SYM")
+        except Exception as e:  # the reference prints and carries on (selfplay_worker.py:126-130)
+            print("EXCEPTION in NoModelSelfPlayWorker!!!: %s" % e)
+            traceback.print_exc(file=sys.stdout)
+
+
+class SelfPlayWorker(Process):
+    def __init__(self, gpuid, forever=False, one_game_only=-1):
+        Process.__init__(self, name='SelfPlayProcessor')
+        self._gpuid = gpuid
+        self._forever = forever
+        self._one_game_only = one_game_only
+
+    def run(self):
+        try:
+            n = 1 if self._one_game_only >= 0 else None
+            run_selfplay(self._gpuid, "BEST", n_games=n)
+        except Exception as e:
+            print("EXCEPTION in SelfPlayWorker!!!: %s" % e)
+            traceback.print_exc(file=sys.stdout)

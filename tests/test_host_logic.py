@@ -1,0 +1,144 @@
+"""CPU-only tests of the host-side logic around the HIP path: game scheduling / resign calibration
+(selfplay_worker.py:82-118), sample writer rules (sgfsave.py:49-79), record unpacking, stub nets."""
+import os
+
+import numpy as np
+
+from tests.helpers import load
+
+
+def test_game_scheduler_reserves_directories(tmp_path):
+    from sejonggo_amd.selfplay_worker import GameScheduler
+    root = str(tmp_path)
+    os.makedirs(os.path.join(root, "m", "game_00001"))       # someone else's game
+    s = GameScheduler(root, "m", 4, 0.1, 0.05, rand=lambda: 0.5)
+    got = [s.reserve() for _ in range(5)]
+    assert got == [0, 2, 3, None, None]
+    assert os.path.isdir(os.path.join(root, "m", "game_00003"))
+    s.discard(3)
+    assert not os.path.isdir(os.path.join(root, "m", "game_00003"))
+
+
+def test_resign_threshold_matches_reference_rule():
+    """selfplay_worker.py:100-112: arrival-order list, index int(0.05 * len), winner's values only."""
+    from sejonggo_amd.selfplay_worker import GameScheduler
+    s = GameScheduler("/nonexistent", "m", 0, 0.10, 0.05, rand=lambda: 0.5)
+    assert s.pick_resign() is None
+    rng = np.random.RandomState(0)
+    mins = []
+    for g in range(45):
+        moves = [{'value': np.float32(v)} for v in rng.uniform(-1, 1, size=10)]
+        winner = 1 if g % 2 == 0 else 0
+        s.finished({'moves': moves, 'winner': winner}, None)
+        vals = [m['value'] for m in (moves[::2] if winner == 1 else moves[1::2])]
+        mins.append(min(vals))
+        idx = int(0.05 * len(mins))
+        want = mins[idx] if idx > 0 else None
+        if idx > 0:
+            assert s.current_resign == want
+    assert s.pick_resign() == s.current_resign
+    s.rand = lambda: 0.05            # 10 % of games play without resignation
+    assert s.pick_resign() is None
+    before = list(s.min_values)
+    s.finished({'moves': [{'value': np.float32(-1)}] * 4, 'winner': 1}, resign=-0.9)   # resign games do not calibrate
+    assert s.min_values == before
+
+
+def test_value_target_compat_and_corrected():
+    from sejonggo_amd.sgfsave import value_target
+    # reference rule (sgfsave.py:56): winner in {1, 0, None}, player in {+1, -1}
+    assert value_target(1, 1, 0, compat=True) == 1 and value_target(1, -1, 1, compat=True) == -1
+    assert value_target(0, 1, 0, compat=True) == -1 and value_target(0, -1, 1, compat=True) == -1   # white wins: all -1
+    assert value_target(None, 1, 0, compat=True) == -1
+    assert value_target(0, 0, 1, compat=False) == 1 and value_target(0, 0, 2, compat=False) == -1
+    assert value_target(None, 0, 3, compat=False) == 0
+
+
+def test_sample_writer_layout(tmp_path):
+    from sejonggo_amd import sgfsave
+    from sejonggo_amd.conf import conf
+    old = conf['SELF_PLAY_DIR']
+    conf['SELF_PLAY_DIR'] = str(tmp_path)
+    try:
+        S = 9
+        gd = {'winner': 1, 'moves': [{'board': np.ones((1, S, S, 17), np.int32), 'policy': np.full(S * S + 1, 0.5), 'player': 1,
+                                      'move_n': k, 'value': np.float32(0.1)} for k in range(3)]}
+        sgfsave.save_self_play_data("model_0", 7, gd)
+        d = os.path.join(str(tmp_path), "model_0", "game_00007", "move_002")
+        assert os.path.isdir(d)
+        if sgfsave.HAVE_H5:
+            import h5py
+            with h5py.File(os.path.join(d, "sample.h5")) as f:
+                b, p, v = f['board'][:], f['policy_target'][:], f['value_target'][()]
+        else:
+            z = np.load(os.path.join(d, "sample.npz"))
+            b, p, v = z['board'], z['policy_target'], z['value_target']
+        assert b.shape == (1, S, S, 17) and b.dtype == np.float32
+        assert p.shape == (S * S + 1,) and p.dtype == np.float32 and v.dtype == np.float32 and v.shape == () and v == 1
+    finally:
+        conf['SELF_PLAY_DIR'] = old
+
+
+def test_unpack_positions_inverts_the_packed_layout():
+    from sejonggo_amd.engine import unpack_positions
+    rng = np.random.RandomState(1)
+    for S in (5, 9, 19):
+        N = S * S
+        NW = (N + 31) // 32
+        RW = ((16 * NW + 1 + 3) // 4) * 4
+        boards = np.zeros((6, S, S, 17), np.int32)
+        boards[..., :16] = rng.randint(0, 2, size=(6, S, S, 16))
+        boards[..., 16] = rng.choice([-1, 1], size=6)[:, None, None]
+        packed = np.zeros((6, RW), np.uint32)
+        for b in range(6):
+            for c in range(16):
+                bits = boards[b, :, :, c].reshape(-1)
+                for a in np.flatnonzero(bits):
+                    packed[b, c * NW + (a >> 5)] |= np.uint32(1 << (a & 31))
+            packed[b, 16 * NW] = 1 if boards[b, 0, 0, 16] == -1 else 0
+        assert np.array_equal(unpack_positions(packed, S), boards)
+
+
+def test_stub_nets_numpy_equals_torch():
+    import torch
+    from sejonggo_amd.stub_nets import make_stub
+    rng = np.random.RandomState(2)
+    for kind in ("uniform", "dummy", "hash"):
+        net = make_stub(kind, 9)
+        X = rng.randint(0, 2, size=(5, 9, 9, 17)).astype(np.int32)
+        X[..., 16] = -1
+        p1, v1 = net.predict_on_batch(X)
+        p2, v2 = net.predict_on_batch(torch.from_numpy(X).to(torch.float16))
+        assert p1.dtype == np.float32 and p1.tobytes() == p2.numpy().tobytes()
+        assert v1.tobytes() == v2.numpy().tobytes()
+
+
+def test_dummy_net_restates_reference_dummy_model():
+    """DummyModel (test/tests.py:34-49): policy proportional to reversed(range(1, A+1)), value 1."""
+    from sejonggo_amd.stub_nets import DummyNet
+    p, v = DummyNet(9).predict_on_batch(np.zeros((2, 9, 9, 17), np.float32))
+    want = np.array(list(reversed(range(1, 83))), dtype=np.float32)
+    want /= want.sum()
+    assert np.allclose(p[0], want, rtol=0, atol=1e-9) and (v == 1).all()
+    z = load("async_01.npz")   # the golden game played with it has value == 1 at every root
+    assert (z["move_value"] == 1).all()
+
+
+def test_net_contract_and_bn_folding():
+    import torch
+    from sejonggo_amd.net import PolicyValueNet
+    torch.manual_seed(0)
+    net = PolicyValueNet(9, 2, 16).eval()
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.2)
+            m.running_var.uniform_(0.5, 2.0)
+    X = torch.randint(-1, 2, (3, 9, 9, 17)).float()
+    p, v = net.predict_on_batch(X)
+    assert p.shape == (3, 82) and v.shape == (3, 1) and torch.allclose(p.sum(1), torch.ones(3), atol=1e-5)
+    assert (v.abs() <= 1).all()
+    p2, v2 = net.fused(torch.float32).predict_on_batch(X)
+    assert float((p - p2).abs().max()) < 1e-6 and float((v - v2).abs().max()) < 1e-5
+    # reference topology: 'valid' stem => tower is (S-2)^2 ; FLOPs as SURVEY.md §8d counts them
+    assert PolicyValueNet(19, 20, 256).tower_side == 17
+    assert abs(PolicyValueNet(19, 20, 256).flops_per_eval() / 1e9 - 13.66) < 0.01
