@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--channels", type=int, default=256)
     ap.add_argument("--symmetry", default="random1", choices=["random1", "avg8", "identity"])
     ap.add_argument("--net", default="resnet", choices=["resnet", "uniform", "hash"])
+    ap.add_argument("--plain-net", type=int, default=0, help="1: plain PyTorch module instead of the fused inference net")
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--cpu-games", type=int, default=2)
     ap.add_argument("--cpu-moves", type=int, default=1)
@@ -112,12 +113,15 @@ def main():
         torch.cuda.set_device(0)
         local = 0
     from sejonggo_amd.engine import SelfPlayEngine
-    from sejonggo_amd.net import build_net
+    from sejonggo_amd.net import build_net, build_fused_net
     from sejonggo_amd.stub_nets import make_stub
     from sejonggo_amd.distributed import tuple_dtype, gather_tuples
     S, G, sims, E = args.size, args.games, args.sims, args.energy
     if args.net == "resnet":
-        net = build_net(S, args.blocks, args.channels, name="bench_%db" % args.blocks, seed=0, device="cuda")
+        if args.plain_net:
+            net = build_net(S, args.blocks, args.channels, name="bench_%db" % args.blocks, seed=0, device="cuda")
+        else:
+            net, _ = build_fused_net(S, args.blocks, args.channels, name="bench_%db" % args.blocks, seed=0, device="cuda")
     else:
         net = make_stub(args.net, S)
     eng = SelfPlayEngine(net, size=S, n_games=G, sims=sims, energy=E, stop_exploration=30, symmetry=args.symmetry,

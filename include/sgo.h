@@ -84,9 +84,16 @@ int sgo_legal_dev(int S, int n, const uint32_t *d_packed, const int32_t *d_idx, 
 int sgo_score_dev(int S, int n, const uint32_t *d_packed, const int32_t *d_idx, double komi, int32_t *d_result,
                   void *stream);
 /* nn_input_pack (+ fused sym_apply): network input for positions d_packed[d_idx[i]], transformed by
- * symmetry k.  layout 0: NHWC [n][S][S][17], 1: NCHW [n][17][S][S]; dtype 0: fp16, 1: fp32. */
+ * symmetry k.  layout 0: NHWC [n][S][S][17], 1: NCHW [n][17][S][S], 2: NHWC with the channels zero-padded
+ * to 32 [n][S][S][32] (MFMA-friendly K for the stem convolution); dtype 0: fp16, 1: fp32. */
 int sgo_nn_pack_dev(int S, int n, const uint32_t *d_packed, const int32_t *d_idx, int k, int layout, int dtype,
                     void *d_out, void *stream);
+
+/* Fused convolution epilogue of the resident net (model.py:37-46 BatchNorm folded into the conv, then
+ * Activation('relu') / Add()): out = relu(x + bias[c] (+ skip)) on NHWC fp16, in place allowed.
+ * n_elems and channels must be multiples of 8. */
+int sgo_bias_act_dev(long n_elems, int channels, const void *d_x, const void *d_bias, const void *d_skip, void *d_out,
+                     void *stream);
 
 /* ---- self-play engine: virtual-loss PUCT + game loop, many games resident on one GPU ------------ */
 /* Replaces nomodel_self_play.py:59-82 async_simulate2, :114-140 select_play, :142-271 play_game_async,

@@ -175,6 +175,12 @@ __global__ __launch_bounds__(256) void k_nn_pack(int n, const uint32_t *packed, 
         T *o = out + ((size_t)e * G::N + pt) * 17;
 #pragma unroll
         for (int c = 0; c < 17; c++) o[c] = vals[c];
+    } else if (layout == 2) {  // NHWC, channels zero-padded to 32 (MFMA-friendly K for the stem convolution)
+        T *o = out + ((size_t)e * G::N + pt) * 32;
+#pragma unroll
+        for (int c = 0; c < 17; c++) o[c] = vals[c];
+#pragma unroll
+        for (int c = 17; c < 32; c++) o[c] = (T)0.0f;
     } else {  // NCHW
         T *o = out + (size_t)e * 17 * G::N + pt;
 #pragma unroll
@@ -207,6 +213,21 @@ __global__ void k_legal_to_mask(int A, int NW, int n, const uint32_t *legal, uin
     int b = gid / A, a = gid - b * A;
     uint32_t bit = (legal[(size_t)b * NW + (a >> 5)] >> (a & 31)) & 1u;
     mask[gid] = bit ? 0 : 1;  // the reference's mask: 1 = illegal
+}
+
+// Fused convolution epilogue for the resident net: out = relu(x + bias[c] (+ skip)), NHWC fp16, 8 halves
+// (16 B) per thread.  One pass instead of MIOpen's separate bias / add / clamp passes.
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void k_bias_act(long n8, int C8, const half8_t *x, const half8_t *bias,
+                                                  const half8_t *skip, half8_t *out) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    const half8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (; i < n8; i += stride) {
+        half8_t r = x[i] + bias[i % C8];
+        if (skip) r = r + skip[i];
+        out[i] = __builtin_elementwise_max(r, zero);
+    }
 }
 
 // ------------------------------------------------------------------------------------ launchers
@@ -322,11 +343,28 @@ int sgo_score_dev(int S, int n, const uint32_t *d_packed, const int32_t *d_idx, 
 }
 int sgo_nn_pack_dev(int S, int n, const uint32_t *d_packed, const int32_t *d_idx, int k, int layout, int dtype,
                     void *d_out, void *stream) {
-    if (!size_ok(S) || k < 0 || k > 7 || layout < 0 || layout > 1 || dtype < 0 || dtype > 1) {
+    if (!size_ok(S) || k < 0 || k > 7 || layout < 0 || layout > 2 || dtype < 0 || dtype > 1) {
         set_error("sgo_nn_pack_dev: bad argument");
         return SGO_ERR_ARG;
     }
     return launch_nn_pack(S, n, d_packed, d_idx, k, layout, dtype, d_out, (hipStream_t)stream);
+}
+
+int sgo_bias_act_dev(long n_elems, int channels, const void *d_x, const void *d_bias, const void *d_skip, void *d_out,
+                     void *stream) {
+    if (n_elems < 0 || channels <= 0 || channels % 8 || n_elems % 8 || !d_x || !d_bias || !d_out) {
+        set_error("sgo_bias_act_dev: sizes must be multiples of 8 halves");
+        return SGO_ERR_ARG;
+    }
+    if (n_elems == 0) return SGO_OK;
+    const long n8 = n_elems / 8;
+    long blocks = (n8 + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    k_bias_act<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(n8, channels / 8, (const half8_t *)d_x,
+                                                                               (const half8_t *)d_bias, (const half8_t *)d_skip,
+                                                                               (half8_t *)d_out);
+    SGO_HIP(hipGetLastError());
+    return SGO_OK;
 }
 
 // ---- host-buffer API (drop-in for play.py / symmetry.py)

@@ -60,7 +60,9 @@ class SelfPlayEngine(object):
         self.alpha = conf['DIRICHLET_ALPHA'] if dirichlet_alpha is None else dirichlet_alpha
         self.symmetry = symmetry
         assert symmetry in ("identity", "random1", "avg8") or symmetry in range(8)  # int k: always that symmetry
-        self.layout = {"nhwc": 0, "nchw": 1}[layout]
+        if layout == "nhwc" and getattr(net, "in_channels", 17) == 32:
+            layout = "nhwc32"          # the fused inference net takes the channel-padded input
+        self.layout = {"nhwc": 0, "nchw": 1, "nhwc32": 2}[layout]
         self.dtype = {"fp16": 0, "fp32": 1}[dtype]
         self.device = torch.device("cuda", device)
         torch.cuda.set_device(self.device)
@@ -77,7 +79,7 @@ class SelfPlayEngine(object):
         self.pyrng = pyrandom.Random(seed)
         max_eval = self.G * self.E
         tdt = torch.float16 if self.dtype == 0 else torch.float32
-        shape = (max_eval, self.S, self.S, 17) if self.layout == 0 else (max_eval, 17, self.S, self.S)
+        shape = {0: (max_eval, self.S, self.S, 17), 1: (max_eval, 17, self.S, self.S), 2: (max_eval, self.S, self.S, 32)}[self.layout]
         self.nn_in = torch.zeros(shape, dtype=tdt, device=self.device)
         self.status = _lib.Status()
         self._policy = None

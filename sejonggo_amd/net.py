@@ -124,3 +124,90 @@ def build_net(size, n_blocks, channels=256, name="model_0", seed=0, device="cuda
             mod.running_var.uniform_(0.5, 1.5)
     net.eval()
     return net.fused(dtype).to(device)
+
+
+class FusedInferenceNet(object):
+    """Inference-only form of PolicyValueNet for the engine's hot loop (same weights, same contract):
+
+    * input NHWC fp16 with channels zero-padded 17 -> 32 (k_nn_pack layout 2), so the stem runs on an
+      MFMA-friendly K instead of MIOpen's slow path for odd channel counts;
+    * every 3x3 convolution is a bias-free MIOpen/CK implicit GEMM followed by ONE hand-written epilogue pass
+      (libsgo_hip.so k_bias_act: bias + optional skip + ReLU) instead of separate bias / add / clamp passes;
+    * both 1x1 head convolutions are one [n*t*t, C] x [C, 4] GEMM on the channels-last view.
+    """
+    in_channels = 32
+
+    def __init__(self, net, dtype=torch.float16, device="cuda"):
+        from . import _lib
+        self._lib = _lib
+        self.lib = _lib.require_gpu()
+        assert dtype == torch.float16, "the fused epilogue kernel is fp16"
+        f = net if net._fused else net.fused(torch.float32)
+        f = f.float()
+        self.name = net.name
+        self.size, self.A, self.t = net.size, net.A, net.tower_side
+        self.channels = f.stem.out_channels
+        dev = torch.device(device)
+        self.device = dev
+
+        def cw(w):
+            return w.to(dev, dtype).contiguous(memory_format=torch.channels_last)
+
+        w = torch.zeros(self.channels, 32, 3, 3)
+        w[:, :17] = f.stem.weight
+        self.stem_w, self.stem_b = cw(w), f.stem.bias.to(dev, dtype).contiguous()
+        self.stem_pad = f.stem.padding
+        self.blocks = [(cw(b.conv1.weight), b.conv1.bias.to(dev, dtype).contiguous(),
+                        cw(b.conv2.weight), b.conv2.bias.to(dev, dtype).contiguous()) for b in f.blocks]
+        hw = torch.cat([f.p_conv.weight.reshape(2, -1), f.v_conv.weight.reshape(2, -1)], 0)      # [4, C]
+        hb = torch.cat([f.p_conv.bias, f.v_conv.bias], 0)
+        self.head_w, self.head_b = hw.to(dev, dtype).contiguous(), hb.to(dev, dtype).contiguous()
+        self.p_fc_w, self.p_fc_b = f.p_fc.weight.to(dev, dtype).contiguous(), f.p_fc.bias.to(dev, dtype).contiguous()
+        self.v_fc1_w, self.v_fc1_b = f.v_fc1.weight.to(dev, dtype).contiguous(), f.v_fc1.bias.to(dev, dtype).contiguous()
+        self.v_fc2_w, self.v_fc2_b = f.v_fc2.weight.to(dev, dtype).contiguous(), f.v_fc2.bias.to(dev, dtype).contiguous()
+        self._flops = net.flops_per_eval()
+
+    def flops_per_eval(self):
+        return self._flops
+
+    def _epilogue(self, y, bias, skip=None):
+        L = self._lib
+        L.check(self.lib.sgo_bias_act_dev(y.numel(), y.shape[1], y.data_ptr(), bias.data_ptr(),
+                                          None if skip is None else skip.data_ptr(), y.data_ptr(),
+                                          torch.cuda.current_stream().cuda_stream), "sgo_bias_act_dev")
+        return y
+
+    @torch.no_grad()
+    def predict_on_batch(self, X):
+        """X: [n,S,S,32] fp16 CUDA (channel-padded NHWC) or [n,S,S,17] (padded here)."""
+        if not torch.is_tensor(X):
+            import numpy as np
+            X = torch.from_numpy(np.ascontiguousarray(X))
+        X = X.to(self.device, torch.float16)
+        if X.shape[-1] == 17:
+            X = F.pad(X, (0, 15))
+        n = X.shape[0]
+        x = X.permute(0, 3, 1, 2)                                 # NCHW view of channels-last memory
+        y = self._epilogue(F.conv2d(x, self.stem_w, None, padding=self.stem_pad), self.stem_b)
+        for (w1, b1, w2, b2) in self.blocks:
+            z = self._epilogue(F.conv2d(y, w1, None, padding=1), b1)
+            y = self._epilogue(F.conv2d(z, w2, None, padding=1), b2, skip=y)
+        t2 = self.t * self.t
+        h = F.relu(F.linear(y.permute(0, 2, 3, 1).reshape(n * t2, self.channels), self.head_w, self.head_b))
+        h = h.reshape(n, t2, 4)
+        p = h[:, :, 0:2].reshape(n, 2 * t2)                       # Keras Flatten of [t, t, 2]
+        v = h[:, :, 2:4].reshape(n, 2 * t2)
+        p = torch.softmax(F.linear(p, self.p_fc_w, self.p_fc_b).float(), dim=1)
+        v = torch.tanh(F.linear(F.relu(F.linear(v, self.v_fc1_w, self.v_fc1_b)), self.v_fc2_w, self.v_fc2_b).float())
+        return p, v
+
+
+def build_fused_net(size, n_blocks, channels=256, name="model_0", seed=0, device="cuda"):
+    torch.manual_seed(seed)
+    net = PolicyValueNet(size, n_blocks, channels, name=name)
+    for mod in net.modules():
+        if isinstance(mod, nn.BatchNorm2d):
+            mod.running_mean.normal_(0, 0.1)
+            mod.running_var.uniform_(0.5, 1.5)
+    net.eval()
+    return FusedInferenceNet(net, torch.float16, device), net

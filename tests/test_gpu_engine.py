@@ -200,3 +200,54 @@ def test_capacity_error_is_loud(L):
     with pytest.raises(_lib.SgoError):
         eng.run()
     eng.close()
+
+
+def test_fused_inference_net_matches_fp32_reference(L):
+    """The hot-loop net (padded input, hand-written bias/skip/ReLU epilogue, merged head GEMM) against the
+    plain PyTorch fp32 forward of the same weights.  Tolerance for the fp16 path:
+    max-abs dp <= 2e-3, dv <= 5e-3."""
+    import torch
+    from sejonggo_amd.net import build_fused_net
+    for S, nb, ch in ((9, 3, 64), (19, 2, 256)):
+        fnet, ref = build_fused_net(S, nb, ch, seed=3)
+        ref = ref.cuda().float()
+        X = torch.zeros((16, S, S, 17), device="cuda")
+        X[..., :16] = (torch.rand((16, S, S, 16), device="cuda") < 0.2).float()
+        X[..., 16] = 1.0
+        X[8:, :, :, 16] = -1.0
+        p0, v0 = ref.predict_on_batch(X)
+        p1, v1 = fnet.predict_on_batch(X.half())
+        assert p1.shape == (16, S * S + 1) and v1.shape == (16, 1)
+        assert float((p0 - p1).abs().max()) <= 2e-3, float((p0 - p1).abs().max())
+        assert float((v0 - v1).abs().max()) <= 5e-3, float((v0 - v1).abs().max())
+        Xp = torch.nn.functional.pad(X.half(), (0, 15))
+        p2, v2 = fnet.predict_on_batch(Xp)
+        assert torch.equal(p1, p2) and torch.equal(v1, v2)
+
+
+def test_nn_pack_channel_padded_layout(L):
+    import torch
+    lib = L.load()
+    S, n = 19, 5
+    RW = lib.sgo_packed_words(S)
+    boards = torch.zeros((n, S, S, 17), dtype=torch.int32, device="cuda")
+    boards[..., :16] = (torch.rand((n, S, S, 16), device="cuda") < 0.3).int()
+    boards[..., 16] = -1
+    packed = torch.zeros((n, RW), dtype=torch.int32, device="cuda")
+    st = L.stream_ptr()
+    L.check(lib.sgo_pack_dev(S, n, L.ptr(boards), L.ptr(packed), st))
+    out = torch.full((n, S, S, 32), 7.0, dtype=torch.float16, device="cuda")
+    L.check(lib.sgo_nn_pack_dev(S, n, L.ptr(packed), None, 0, 2, 0, L.ptr(out), st))
+    assert torch.equal(out[..., :17].int(), boards) and float(out[..., 17:].abs().max()) == 0.0
+
+
+def test_engine_with_fused_net(L):
+    from sejonggo_amd.engine import SelfPlayEngine
+    from sejonggo_amd.net import build_fused_net
+    fnet, _ = build_fused_net(9, 2, 64)
+    eng = SelfPlayEngine(fnet, size=9, n_games=16, sims=16, energy=8, stop_exploration=2, num_moves=4)
+    assert eng.layout == 2
+    eng.start_games(np.arange(16))
+    games = eng.run()
+    assert len(games) == 16 and all(len(g["moves"]) == 4 for g in games)
+    eng.close()
