@@ -900,7 +900,7 @@ int sgo_step(sgo_ctx *x, const float *d_policy, const float *d_value, int sym_k,
 int sgo_collect(sgo_ctx *x, int sym_k, int layout, int dtype, void *d_nn_in, void *stream) {
     if (!x || !d_nn_in) { set_error("sgo_collect: bad argument"); return SGO_ERR_ARG; }
     Ctx &c = x->c;
-    if (sym_k < 0 || sym_k > 7 || layout < 0 || layout > 1 || dtype < 0 || dtype > 1) { set_error("sgo_collect: bad argument"); return SGO_ERR_ARG; }
+    if (sym_k < 0 || sym_k > 7 || layout < 0 || layout > 2 || dtype < 0 || dtype > 1) { set_error("sgo_collect: bad argument"); return SGO_ERR_ARG; }
     return launch_nn_pack(c.S, c.last_n_eval, c.pos, c.evalIdx, sym_k, layout, dtype, d_nn_in, (hipStream_t)stream);
 }
 

