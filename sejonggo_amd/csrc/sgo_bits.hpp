@@ -380,6 +380,41 @@ SGO_DEV int advance_record(const uint32_t *in, uint32_t *out, int a, bool swap_f
     return 0;
 }
 
+// The same ply WITHOUT the history planes: reads planes 0,1 + meta of `in`, writes planes 0,1 + meta of
+// `out` and the legal set.  Planes 2..15 are moved by the separate streaming kernel k_history_shift (only
+// valid when in and out do not alias).
+template <int S>
+SGO_DEV int advance_planes(const uint32_t *in, uint32_t *out, int a, bool swap_first, uint32_t *legal_out) {
+    using G = Geo<S>;
+    if (a < 0 || a > G::N) return -102;
+    uint32_t w0[G::NW], w1[G::NW];
+    load_plane<S>(in, swap_first ? 1 : 0, w0);
+    load_plane<S>(in, swap_first ? 0 : 1, w1);
+    const uint32_t meta = in[G::META];
+    uint32_t own[S], opp[S], before_opp[S];
+    unpack_rows<S>(w0, own);
+    unpack_rows<S>(w1, opp);
+#pragma unroll
+    for (int y = 0; y < S; y++) before_opp[y] = opp[y];
+    int st = advance_core<S>(own, opp, a);
+    if (st) return st;
+    uint32_t n0[G::NW], n1[G::NW];
+    pack_rows<S>(opp, n0);
+    pack_rows<S>(own, n1);
+    store_plane<S>(out, 0, n0);
+    store_plane<S>(out, 1, n1);
+    out[G::META] = (meta & ~1u) | ((meta & 1u) ^ (swap_first ? 1u : 0u) ^ 1u);
+    if (legal_out) {
+        uint32_t legal[S], lw[G::NW];
+        legal_core<S>(opp, own, before_opp, legal);
+        pack_rows<S>(legal, lw);
+        lw[G::N >> 5] |= 1u << (G::N & 31);
+#pragma unroll
+        for (int i = 0; i < G::NW; i++) legal_out[i] = lw[i];
+    }
+    return 0;
+}
+
 template <int S>
 SGO_DEV void legal_record(const uint32_t *rec, uint32_t *legal_out) {
     using G = Geo<S>;

@@ -38,6 +38,10 @@ void build_sym_lut(int S, int k, int32_t *lut);
 int launch_advance_legal(int S, int n, const uint32_t *d_in, const int32_t *d_in_idx, const int32_t *d_moves,
                          const int32_t *d_colors, uint32_t *d_out, const int32_t *d_out_idx, uint32_t *d_legal,
                          const int32_t *d_legal_idx, int32_t *d_status, hipStream_t st);
+// split form (history stream + register kernel); in/out records must not alias.  d_n (device int) overrides n_max.
+int launch_advance_split(int S, int n_max, const int *d_n, const uint32_t *d_in, const int32_t *d_in_idx,
+                         const int32_t *d_moves, const int32_t *d_colors, uint32_t *d_out, const int32_t *d_out_idx,
+                         uint32_t *d_legal, const int32_t *d_legal_idx, int32_t *d_status, hipStream_t st);
 int launch_nn_pack(int S, int n, const uint32_t *d_packed, const int32_t *d_idx, int k, int layout, int dtype,
                    void *d_out, hipStream_t st);
 int launch_score(int S, int n, const uint32_t *d_packed, const int32_t *d_idx, double komi, int32_t *d_result,

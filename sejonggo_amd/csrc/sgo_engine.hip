@@ -878,8 +878,9 @@ int sgo_step(sgo_ctx *x, const float *d_policy, const float *d_value, int sym_k,
     // board_advance for the new leaves, bracketed by HIP events on this stream
     SGO_HIP(hipEventRecord(x->h.ev0, st));
     const int max_leaf = c.G * c.E;
-    SGO_DISPATCH(c.S, k_leaf_advance<kS><<<dim3((max_leaf + 63) / 64), dim3(64), 0, st>>>(c));
-    SGO_HIP(hipGetLastError());
+    // parents (leafIn) and freshly allocated blocks (leafOut) are disjoint block sets => split form
+    CK(launch_advance_split(c.S, max_leaf, &c.dstatus->n_leaf, c.pos, c.leafIn, c.leafMv, nullptr, c.pos, c.leafOut, c.legal,
+                            c.leafOut, nullptr, st));
     SGO_HIP(hipEventRecord(x->h.ev1, st));
     SGO_HIP(hipMemcpyAsync(c.hstatus, c.dstatus, sizeof(DevStatus), hipMemcpyDeviceToHost, st));
     SGO_HIP(hipStreamSynchronize(st));

@@ -19,6 +19,8 @@
 
 namespace sgo {
 
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
 // ------------------------------------------------------------------------------------ errors
 static thread_local std::string g_err;
 void set_error(const std::string &msg) { g_err = msg; }
@@ -94,6 +96,84 @@ __global__ __launch_bounds__(256) void k_advance_legal(int n, const uint32_t *in
         if (c != 0 && c != mover) { swap_first = true; mover = -mover; }
     }
     int st = advance_record<S>(src, dst, moves[i], swap_first, lg);
+    if (status) status[i] = st ? st : mover;
+}
+
+// ---- split form of board_advance for non-aliasing in/out (the engine's leaf step, dense out-of-place batches)
+// k_history_shift: pure streaming move of the 14 history planes (new plane p <- old plane p-1 / p-3, i.e. the
+// reference's shift + pair swap), one thread per 16-B chunk (4-B word when a plane is not a multiple of 16 B):
+// consecutive threads touch consecutive chunks of one record, so every wave instruction covers whole records.
+template <int S>
+__global__ __launch_bounds__(256) void k_history_shift(int n, const int *n_dev, const uint32_t *in, const int32_t *in_idx,
+                                                       const int32_t *colors, uint32_t *out, const int32_t *out_idx) {
+    using G = Geo<S>;
+    constexpr bool V4 = (G::NW % 4 == 0);
+    constexpr int CPP = V4 ? G::NW / 4 : G::NW;   // chunks per plane
+    constexpr int CPR = 14 * CPP;                 // chunks per record
+    if (n_dev) n = *n_dev;
+    const long total = (long)n * CPR;
+    const long stride = (long)gridDim.x * blockDim.x;
+    auto addr = [&](long t, const uint32_t *&sp_, uint32_t *&dp_) {
+        const int i = (int)(t / CPR), c = (int)(t - (long)i * CPR);
+        const int p = 2 + c / CPP, w = c - (p - 2) * CPP;
+        const uint32_t *src = in + (size_t)(in_idx ? in_idx[i] : i) * G::RW;
+        uint32_t *dst = out + (size_t)(out_idx ? out_idx[i] : i) * G::RW;
+        bool swap_first = false;
+        if (colors) {
+            const int mover = (src[G::META] & 1u) ? -1 : 1;
+            const int col = colors[i];
+            swap_first = (col != 0 && col != mover);
+        }
+        const int sp = swap_first ? p - 2 : ((p & 1) ? p - 3 : p - 1);
+        constexpr int WPC = V4 ? 4 : 1;
+        sp_ = src + sp * G::NW + w * WPC;
+        dp_ = dst + p * G::NW + w * WPC;
+    };
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += 4 * stride) {
+        // four independent chunks in flight per thread
+        const uint32_t *s0, *s1, *s2, *s3;
+        uint32_t *d0, *d1, *d2, *d3;
+        const bool b1 = t + stride < total, b2 = t + 2 * stride < total, b3 = t + 3 * stride < total;
+        addr(t, s0, d0);
+        addr(b1 ? t + stride : t, s1, d1);
+        addr(b2 ? t + 2 * stride : t, s2, d2);
+        addr(b3 ? t + 3 * stride : t, s3, d3);
+        if constexpr (V4) {
+            uint4 v0 = *reinterpret_cast<const uint4 *>(s0), v1 = *reinterpret_cast<const uint4 *>(s1);
+            uint4 v2 = *reinterpret_cast<const uint4 *>(s2), v3 = *reinterpret_cast<const uint4 *>(s3);
+            *reinterpret_cast<uint4 *>(d0) = v0;
+            if (b1) *reinterpret_cast<uint4 *>(d1) = v1;
+            if (b2) *reinterpret_cast<uint4 *>(d2) = v2;
+            if (b3) *reinterpret_cast<uint4 *>(d3) = v3;
+        } else {
+            uint32_t v0 = *s0, v1 = *s1, v2 = *s2, v3 = *s3;
+            *d0 = v0;
+            if (b1) *d1 = v1;
+            if (b2) *d2 = v2;
+            if (b3) *d3 = v3;
+        }
+    }
+}
+
+template <int S>
+__global__ __launch_bounds__(64) void k_advance_planes(int n, const int *n_dev, const uint32_t *in, const int32_t *in_idx,
+                                                       const int32_t *moves, const int32_t *colors, uint32_t *out,
+                                                       const int32_t *out_idx, uint32_t *legal, const int32_t *legal_idx,
+                                                       int32_t *status) {
+    using G = Geo<S>;
+    if (n_dev) n = *n_dev;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t *src = in + (size_t)(in_idx ? in_idx[i] : i) * G::RW;
+    uint32_t *dst = out + (size_t)(out_idx ? out_idx[i] : i) * G::RW;
+    uint32_t *lg = legal ? legal + (size_t)(legal_idx ? legal_idx[i] : i) * G::NW : nullptr;
+    bool swap_first = false;
+    int mover = (src[G::META] & 1u) ? -1 : 1;
+    if (colors) {
+        int c = colors[i];
+        if (c != 0 && c != mover) { swap_first = true; mover = -mover; }
+    }
+    int st = advance_planes<S>(src, dst, moves[i], swap_first, lg);
     if (status) status[i] = st ? st : mover;
 }
 
@@ -231,12 +311,37 @@ __global__ __launch_bounds__(256) void k_bias_act(long n8, int C8, const half8_t
 }
 
 // ------------------------------------------------------------------------------------ launchers
-static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Two launches on the caller's stream: the streaming history move, then the register kernel.  (Running the two
+// on separate streams was measured: they contend for the memory system at low stone density and the fork/join
+// events cost more than the overlap saves at the engine's 8 192-leaf launches.)
+int launch_advance_split(int S, int n_max, const int *d_n, const uint32_t *d_in, const int32_t *d_in_idx,
+                         const int32_t *d_moves, const int32_t *d_colors, uint32_t *d_out, const int32_t *d_out_idx,
+                         uint32_t *d_legal, const int32_t *d_legal_idx, int32_t *d_status, hipStream_t st) {
+    if (n_max <= 0) return SGO_OK;
+    SGO_DISPATCH(S, {
+        constexpr int CPR = 14 * ((Geo<kS>::NW % 4 == 0) ? Geo<kS>::NW / 4 : Geo<kS>::NW);
+        long blocks = ((long)n_max * CPR + 1023) / 1024;
+        if (blocks > 256 * 16) blocks = 256 * 16;
+        if (blocks < 1) blocks = 1;
+        k_history_shift<kS><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(n_max, d_n, d_in, d_in_idx, d_colors, d_out, d_out_idx);
+        k_advance_planes<kS><<<dim3(cdiv(n_max, 64)), dim3(64), 0, st>>>(n_max, d_n, d_in, d_in_idx, d_moves, d_colors, d_out,
+                                                                         d_out_idx, d_legal, d_legal_idx, d_status);
+    });
+    SGO_HIP(hipGetLastError());
+    return SGO_OK;
+}
 
 int launch_advance_legal(int S, int n, const uint32_t *d_in, const int32_t *d_in_idx, const int32_t *d_moves,
                          const int32_t *d_colors, uint32_t *d_out, const int32_t *d_out_idx, uint32_t *d_legal,
                          const int32_t *d_legal_idx, int32_t *d_status, hipStream_t st) {
     if (n <= 0) return SGO_OK;
+    const size_t rw = (size_t)sgo_packed_words(S);
+    // dense, provably non-overlapping in/out => streaming history move + register kernel; anything that may alias
+    // (in place, index lists) => the fused per-lane kernel, which is safe record-for-record in place
+    if (!d_in_idx && !d_out_idx && (d_out + (size_t)n * rw <= d_in || d_in + (size_t)n * rw <= d_out) && size_ok(S))
+        return launch_advance_split(S, n, nullptr, d_in, nullptr, d_moves, d_colors, d_out, nullptr, d_legal, d_legal_idx,
+                                    d_status, st);
     // 64-thread blocks: a block is one wavefront = 64 positions, so small batches still spread over CUs
     SGO_DISPATCH(S, k_advance_legal<kS><<<dim3(cdiv(n, 64)), dim3(64), 0, st>>>(n, d_in, d_in_idx, d_moves, d_colors, d_out, d_out_idx, d_legal, d_legal_idx, d_status));
     SGO_HIP(hipGetLastError());
