@@ -38,8 +38,10 @@ def parse():
     ap.add_argument("--symmetry", default="random1", choices=["random1", "avg8", "identity"])
     ap.add_argument("--net", default="resnet", choices=["resnet", "uniform", "hash"])
     ap.add_argument("--plain-net", type=int, default=0, help="1: plain PyTorch module instead of the fused inference net")
+    ap.add_argument("--saturated", type=int, default=1, help="also time board_advance on a chip-filling dense batch")
     ap.add_argument("--cpu-baseline", type=int, default=1)
-    ap.add_argument("--cpu-games", type=int, default=2)
+    ap.add_argument("--cpu-games", type=int, default=4)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="wall-clock budget of the CPU baseline sample")
     ap.add_argument("--cpu-moves", type=int, default=1)
     return ap.parse_args()
 
@@ -68,9 +70,12 @@ def cpu_baseline(args, size, sims, energy, n_blocks, channels, symmetry):
     games = [ora.Game(size, sims, energy, 30, nm, uniforms=rng.random_sample(nm + 1),
                       noises=rng.dirichlet([0.03] * (size * size + 1), size=1)) for _ in range(ng)]
     ks = list(range(8)) if symmetry == "avg8" else [0]
+    evals_per_position = (sims // energy) * energy + 1
+    budget = args.cpu_seconds
     t0 = time.time()
     evals = 0
-    while any(g.phase != ora.PH_DONE for g in games):
+    ticks = 0
+    while any(g.phase != ora.PH_DONE for g in games) and time.time() - t0 < budget:
         pend = [(g, g.pending().copy()) for g in games if g.phase != ora.PH_DONE]
         boards = np.concatenate([b for _, b in pend])
         pol, val = None, None
@@ -86,15 +91,64 @@ def cpu_baseline(args, size, sims, energy, n_blocks, channels, symmetry):
         pol = (pol / len(ks)).astype(np.float32)
         val = (val / len(ks)).astype(np.float32)
         evals += len(boards)
+        ticks += 1
         o = 0
         for g, b in pend:
             g.submit(pol[o:o + len(b)], val[o:o + len(b)])
             o += len(b)
     dt = time.time() - t0
-    positions = sum(g.n_moves for g in games)
+    # positions = completed moves + the completed fraction of the moves in flight (every position costs
+    # evals_per_position network evaluations, which is where the CPU time goes)
+    positions = evals / float(evals_per_position)
     return {"value": positions / dt, "unit": "positions/sec", "cores": cores, "kind": "port",
-            "sample": "%d concurrent games x %d move(s) (%d net evals), oracle C rules+tree (1 thread) + torch CPU fp32 "
-                      "net on %d threads, %.1f s" % (ng, nm, evals, cores, dt)}
+            "sample": "%d concurrent games, first %d engine ticks (%d net evals = %.2f positions' worth) in a %.0f s budget; "
+                      "oracle C rules+tree (1 thread) + the same net on torch CPU fp32 (%d threads), %.1f s"
+                      % (ng, ticks, evals, positions, budget, cores, dt)}
+
+
+def saturated_advance(S, n=1 << 18, ply=60, iters=10):
+    """board_advance through the dense C-ABI entry point on a batch large enough to fill the chip (the in-situ
+    launch holds only games*energy leaves).  Positions come from seeded random legal playouts on the GPU."""
+    import torch
+    from sejonggo_amd import _lib as L
+    lib = L.require_gpu()
+    A, NW, RW = S * S + 1, lib.sgo_plane_words(S), lib.sgo_packed_words(S)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(1234)
+    cur = torch.zeros((n, RW), dtype=torch.int32, device="cuda")
+    nxt = torch.zeros_like(cur)
+    legal = torch.full((n, NW), -1, dtype=torch.int32, device="cuda")
+    legal[:, NW - 1] = (1 << ((A - 1) % 32 + 1)) - 1
+    shifts = torch.arange(32, device="cuda", dtype=torch.int32)
+    st = L.stream_ptr()
+
+    def moves():
+        out = torch.empty(n, dtype=torch.int32, device="cuda")
+        for o in range(0, n, 1 << 16):
+            lg = legal[o:o + (1 << 16)]
+            bits = ((lg.unsqueeze(-1) >> shifts) & 1).reshape(lg.shape[0], NW * 32)[:, :A].float()
+            bits[:, A - 1] = 0.01
+            out[o:o + (1 << 16)] = torch.multinomial(bits, 1, generator=g).reshape(-1).to(torch.int32)
+        return out
+
+    for _ in range(ply):
+        mv = moves()
+        L.check(lib.sgo_advance_legal_dev(S, n, L.ptr(cur), None, L.ptr(mv), None, L.ptr(nxt), None, L.ptr(legal), None, st))
+        cur, nxt = nxt, cur
+    mv = moves()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(2):
+        L.check(lib.sgo_advance_legal_dev(S, n, L.ptr(cur), None, L.ptr(mv), None, L.ptr(nxt), None, L.ptr(legal), None, st))
+    e0.record()
+    for _ in range(iters):
+        L.check(lib.sgo_advance_legal_dev(S, n, L.ptr(cur), None, L.ptr(mv), None, L.ptr(nxt), None, L.ptr(legal), None, st))
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    ach = ALGO_BYTES.get(S, 0) * n / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "board_advance (k_history_shift + k_advance_planes), dense batch", "achieved": ach,
+            "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "positions_per_launch": n, "avg_launch_ms": ms,
+            "inputs": "seeded random legal playouts, ply %d" % ply}
 
 
 def main():
@@ -191,7 +245,7 @@ def main():
                                       if args.net == "resnet" else args.net + " stub net", args.symmetry),
                        "games_per_gpu": G, "sims": sims, "energy": E, "net_evals_per_position": (sims // E) * E + 1,
                        "sharding": "games g -> rank g mod N; RCCL gather of per-step records to rank 0"},
-            "roofline": {"bound": "hbm", "kernel": "k_leaf_advance (board_advance: make_play + legal set)",
+            "roofline": {"bound": "hbm", "kernel": "board_advance = k_history_shift + k_advance_planes (make_play + legal set of the new position)",
                          "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": None, "algorithmic_bytes_per_position": ALGO_BYTES.get(S, 0),
                          "positions_per_launch": per_launch, "avg_launch_ms": avg_ms, "launches": adv_n},
@@ -199,6 +253,19 @@ def main():
                     "achieved_tflops": (evals * sym_mult * flops / dt / 1e12) if flops else None,
                     "peak_tflops": 2500.0, "bound": "mfma"},
         }
+        tr = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.isfile(tr) and (S, G, E) == (19, 1024, 8):
+            try:
+                out["roofline"]["traffic"] = json.load(open(tr)).get("traffic_bytes_per_launch_corrected")
+                out["roofline"]["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
+            except Exception:
+                pass
+        if args.saturated and world == 1:
+            eng.close()
+            try:
+                out["roofline_saturated"] = saturated_advance(S)
+            except Exception as ex:
+                out["roofline_saturated"] = {"error": repr(ex)}
         if args.cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(args, S, sims, E, args.blocks, args.channels, args.symmetry)

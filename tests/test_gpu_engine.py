@@ -252,3 +252,66 @@ def test_engine_with_fused_net(L):
     games = eng.run()
     assert len(games) == 16 and all(len(g["moves"]) == 4 for g in games)
     eng.close()
+
+
+def test_resign_and_no_noise_paths_equal_the_oracle(L):
+    """resign thresholds (nomodel_self_play.py:170-173) and self_play=False (no Dirichlet mix, float32 root)."""
+    from oracle import oracle as ora
+    from sejonggo_amd.engine import SelfPlayEngine
+    from sejonggo_amd.stub_nets import make_stub
+    S, sims, E, nm, G = 9, 32, 8, 30, 12
+    net = make_stub("hash", S)
+    rng = np.random.RandomState(5)
+    uni = rng.random_sample((G, nm))
+    resign = [None, -0.2, 0.0, 0.3, -0.5, 0.9, None, -0.1, 0.1, 0.5, -0.9, 0.7]
+    eng = SelfPlayEngine(net, size=S, n_games=G, sims=sims, energy=E, stop_exploration=4, num_moves=nm, komi=5.5,
+                         symmetry="identity", self_play=False)
+    eng.start_games(np.arange(G), uniforms=uni, resign=resign)
+    games = {gd["slot"]: gd for gd in eng.run()}
+    res = eng.results()
+    n_resigned = 0
+    for s in range(G):
+        g = ora.Game(S, sims, E, 4, nm, self_play=False, uniforms=uni[s], resign=resign[s]).run(net)
+        r = g.result()
+        assert r["end_reason"] == res[s]["end_reason"], s
+        n_resigned += r["end_reason"] == 1
+        assert g.n_moves == len(games[s]["moves"]) == res[s]["n_moves"], s
+        assert r["winner"] == res[s]["winner"] and r["black"] == res[s]["black"] and r["white"] == res[s]["white"]
+        assert r["last_player"] == res[s]["last_player"]
+        for i, mv in enumerate(games[s]["moves"]):
+            m = g.move(i)
+            assert np.array_equal(mv["board"], m["board"]) and mv["policy"].tobytes() == m["policy"].tobytes()
+        if r["end_reason"] == 1:
+            assert games[s]["result"] == "%s+R" % {1: "B", -1: "W"}[r["last_player"]]
+    assert n_resigned >= 3
+    eng.close()
+
+
+def test_selfplay_worker_body_writes_samples(L, tmp_path):
+    """run_selfplay: directory reservation, engine loop with slot restarts, sample files in the reference's layout."""
+    import os
+    from sejonggo_amd import predicting_queue_worker as pq
+    from sejonggo_amd import sgfsave
+    from sejonggo_amd.conf import conf
+    from sejonggo_amd.net import build_fused_net
+    from sejonggo_amd.selfplay_worker import run_selfplay
+    keep = dict(conf)
+    try:
+        conf.update({'SIZE': 9, 'MCTS_SIMULATIONS': 16, 'ENERGY': 8, 'STOP_EXPLORATION': 2, 'N_GAMES': 6,
+                     'SELF_PLAY_DIR': str(tmp_path / "sp"), 'GAMES_PER_GPU': 4})
+        fnet, _ = build_fused_net(9, 1, 32, name="wk")
+        pq.set_model_factory(lambda kind: fnet)
+        seen = []
+        played = run_selfplay(0, "BEST_SYM", n_games=6, games_per_gpu=4, on_game=lambda g, gd: seen.append((g, len(gd['moves']))),
+                              max_steps=3000)
+        assert played == len(seen) and played >= 4
+        for g, n in seen:
+            d = os.path.join(conf['SELF_PLAY_DIR'], "wk", "game_%05d" % g)
+            assert len(os.listdir(d)) == n
+            f = os.path.join(d, "move_000", "sample.h5" if sgfsave.HAVE_H5 else "sample.npz")
+            assert os.path.isfile(f)
+    finally:
+        pq.set_model_factory(None)
+        pq.destroy_predicting_workers([0])
+        conf.clear()
+        conf.update(keep)
