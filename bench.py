@@ -58,6 +58,7 @@ def cpu_baseline(args, size, sims, energy, n_blocks, channels, symmetry):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    cores = min(cores, 16)   # the GPU box grants a 16-CPU share per GPU; more threads only oversubscribe it
     torch.set_num_threads(cores)
     if args.net == "resnet":
         torch.manual_seed(0)
@@ -72,6 +73,7 @@ def cpu_baseline(args, size, sims, energy, n_blocks, channels, symmetry):
     ks = list(range(8)) if symmetry == "avg8" else [0]
     evals_per_position = (sims // energy) * energy + 1
     budget = args.cpu_seconds
+    net.predict_on_batch(np.zeros((ng * energy, size, size, 17), np.float32))   # thread-pool / allocator warm-up, untimed
     t0 = time.time()
     evals = 0
     ticks = 0
