@@ -142,6 +142,8 @@ class FusedInferenceNet(object):
         self._lib = _lib
         self.lib = _lib.require_gpu()
         assert dtype == torch.float16, "the fused epilogue kernel is fp16"
+        # use MIOpen's Find path so the tuned solvers of the in-tree user database are honoured
+        torch.backends.cudnn.benchmark = True
         f = net if net._fused else net.fused(torch.float32)
         f = f.float()
         self.name = net.name
