@@ -40,3 +40,21 @@ def play_game_async(model1_indicator, model2_indicator, energy, stop_exploration
 def select_play(board, energy, mcts_tree, temperature, model_indicator, gpuid):
     raise NotImplementedError("select_play on a host dict tree is served by the GTP row (SURVEY.md §8f row 4); "
                               "the device engine owns its trees -- use play_game_async / SelfPlayEngine")
+
+
+def back_propagation(result, node):
+    """nomodel_self_play.py:40-56 on host dict trees: graft the evaluated leaf at `moves`, then add its value to
+    every ancestor up to the root (same value at every level: no minimax sign flip), clearing busy flags."""
+    from .tree_util import get_node_by_moves
+    leaf, moves = result
+    parent = get_node_by_moves(node, moves[:-1])
+    leaf['virtual_loss'] = 0
+    parent['subtree'][moves[-1]].pop('parent', None)   # detach the placeholder
+    parent['subtree'][moves[-1]] = leaf
+    leaf['parent'] = parent
+    while parent is not None:
+        parent['count'] += 1
+        parent['value'] += leaf['value']
+        parent['mean_value'] = parent['value'] / float(parent['count'])
+        parent['virtual_loss'] = 0
+        parent = parent['parent'] if parent['parent'] else None

@@ -99,3 +99,83 @@ def get_winner(board, komi=None):
     if n == 1:
         return int(w[0]), int(bl[0]), float(wh[0])
     return w, bl, wh
+
+
+# ------------------------------------------------------------------------------------------------------------
+# Host-side dict trees (the reference's public tree-node contract, play.py:376-421: nodes are dicts with the keys
+# index, count, value, mean_value, p, subtree, parent, virtual_loss).  The production search keeps its trees on
+# the GPU (engine.SelfPlayEngine / k_search); these functions serve callers that hold Python dict trees -- the
+# reference's sync path (self_play.py), its unit tests and GTP-style front-ends.  The expensive part of building a
+# node, the legal-move mask, still runs on the GPU (legal_moves above).  Arithmetic follows the reference's scalar
+# expressions so that numpy's scalar promotion gives the same float32 / float64 regime per child.
+# ------------------------------------------------------------------------------------------------------------
+Cpuct = 1
+
+
+def _new_node(index, p, parent):
+    return {'index': index, 'count': 0, 'value': 0, 'mean_value': 0, 'p': p, 'subtree': {}, 'parent': parent,
+            'virtual_loss': 0}
+
+
+def new_subtree(policy, board, parent, add_noise=False):
+    """play.py:391-421: one child per legal action, ascending, prior = raw network output (not renormalised);
+    with add_noise the priors are mixed with Dirichlet noise drawn over ALL actions."""
+    import numpy.ma as ma
+    priors = ma.masked_array(policy, mask=legal_moves(board)).reshape(-1)
+    if add_noise:
+        noise = np.random.dirichlet([conf['DIRICHLET_ALPHA']] * priors.shape[0])
+        priors = (1 - conf['DIRICHLET_EPSILON']) * priors + conf['DIRICHLET_EPSILON'] * noise
+    return {move: _new_node(move, p, parent) for move, p in enumerate(priors) if p is not ma.masked}
+
+
+def new_tree(policy, board, add_noise=False):
+    root = _new_node(-1, 1, None)
+    root['subtree'] = new_subtree(policy, board, parent=root, add_noise=add_noise)
+    return root
+
+
+def _puct(subtree):
+    """(action, child, Q + U) for every child, in dict order; U = Cpuct * p * sqrt(sum N) / (1 + N)."""
+    from math import sqrt
+    total_n = sqrt(sum(child['count'] for child in subtree.values())) or 1
+    for action, child in subtree.items():
+        yield action, child, child['mean_value'] + Cpuct * child['p'] * total_n / (1. + child['count'])
+
+
+def top_one_with_virtual_loss(node):
+    """play.py:308-323: best non-busy child, first index wins ties, {} when every child is busy."""
+    best, best_value = {}, -100
+    for action, child, value in _puct(node['subtree']):
+        if child.get('virtual_loss', 0) > 0:
+            continue
+        if value > best_value:
+            best, best_value = {'action': action, 'node': child}, value
+    return best
+
+
+def top_one_action(subtree):
+    """play.py:325-336."""
+    best = {'action': -1, 'value': -1, 'node': None}
+    for action, child, value in _puct(subtree):
+        if value > best['value']:
+            best = {'action': action, 'value': value, 'node': child}
+    return best
+
+
+def top_n_actions(subtree, top_n):
+    """play.py:338-352: the top_n children by Q + U, descending, earlier index first among equals."""
+    ranked = []
+    for action, child, value in _puct(subtree):
+        if len(ranked) < top_n or value > ranked[-1]['value']:
+            pos = len(ranked)
+            while pos > 0 and ranked[pos - 1]['value'] < value:
+                pos -= 1
+            ranked.insert(pos, {'action': action, 'value': value, 'node': child})
+            del ranked[top_n:]
+    return ranked
+
+
+def tree_depth(tree):
+    if tree['subtree'] is None:
+        return 1
+    return 1 + max([tree_depth(child) for child in tree['subtree'].values()] or [0])

@@ -449,6 +449,93 @@ def child_async(size, sims, energy, net_kind, num_moves, stop_exploration, seed,
         size, sims, energy, net_kind, len(moves), gd["result"], counters["predict"], rec["none_events"]))
 
 
+
+def child_sync(size, sims, batch, net_kind, num_moves, stop_exploration, seed, out):
+    """The sync path (self_play.py:28-163 simulate / mcts_decision / select_play, :164-290 play_game): the path the
+    reference's own MCTS unit tests target.  THREAD_SIMULATION is switched off (same semantics, in-process branch)."""
+    import collections
+    import numpy as np
+    conf = _setup_reference(size, sims, 8)
+    conf["MCTS_BATCH_SIZE"] = batch
+    conf["THREAD_SIMULATION"] = False
+    conf["STOP_EXPLORATION"] = stop_exploration
+    import play
+    import symmetry
+    symmetry.SYMMETRIES = symmetry.SYMMETRIES[0:1]      # identity only, as the reference's MCTSTestCase does
+    import self_play as sp
+    from sejonggo_amd.stub_nets import make_stub
+    S, A = size, size * size + 1
+    net = make_stub(net_kind, size)
+    draw_rng = np.random.RandomState(seed)
+    rec = {"uniforms": [], "noises": []}
+
+    def fake_choice(moves, size=1, p=None):
+        u = draw_rng.random_sample()
+        rec["uniforms"].append(u)
+        cdf = np.cumsum(np.asarray(p, dtype=np.float64))
+        cdf /= cdf[-1]
+        return [moves[int(np.searchsorted(cdf, u, side="right"))]]
+
+    def fake_dirichlet(alpha):
+        g = draw_rng.gamma(alpha[0], size=len(alpha))
+        noise = g / g.sum()
+        rec["noises"].append(noise.astype(np.float64))
+        return noise
+
+    np.random.choice = fake_choice
+    np.random.dirichlet = fake_dirichlet
+    data = {}
+    # ---- (1) simulate() called repeatedly on one tree
+    board, _ = play.game_init()
+    for (x, y) in [(2, 2), (3, 2), (2, 3)][: 3 if size >= 5 else 0]:
+        play.make_play(x, y, board)
+    pol, val = net.predict_on_batch(board)
+    tree = play.new_tree(pol[0], board, add_noise=False)
+    hashes, counts = [], []
+    for it in range(6):
+        sp.simulate(tree, np.copy(board), net, batch, board[0, 0, 0, -1])
+        h, nn, ne = _tree_hash(tree)
+        hashes.append(np.frombuffer(h, dtype=np.uint8))
+        counts.append((nn, ne, int(tree["count"])))
+    data["sim_board"] = _board_i8(board)
+    data["sim_hashes"] = np.array(hashes)
+    data["sim_counts"] = np.array(counts, dtype=np.int64)
+    data["sim_root_value"] = np.array(np.float32(tree["value"]))
+    # ---- (2) a sync play_game
+    per_move = collections.defaultdict(list)
+    orig = sp.select_play
+
+    def wrapped(policy, board, mcts_simulations, mcts_tree, temperature, model):
+        a = orig(policy, board, mcts_simulations, mcts_tree, temperature, model)
+        h, nn, ne = _tree_hash(mcts_tree)
+        per_move["tree_hash"].append(np.frombuffer(h, dtype=np.uint8))
+        per_move["n_nodes"].append(nn)
+        per_move["action"].append(int(a))
+        return a
+
+    sp.select_play = wrapped
+    gd = sp.play_game(net, net, sims, stop_exploration, self_play=True, num_moves=num_moves)
+    moves = gd["moves"]
+    data.update({
+        "size": np.array(size, dtype=np.int32), "sims": np.array(sims, dtype=np.int32), "batch": np.array(batch, dtype=np.int32),
+        "stop_exploration": np.array(stop_exploration, dtype=np.int32), "num_moves": np.array(num_moves, dtype=np.int32),
+        "net": np.frombuffer(net_kind.encode(), dtype=np.uint8), "komi": np.array(5.5),
+        "uniforms": np.array(rec["uniforms"], dtype=np.float64),
+        "noises": np.array(rec["noises"], dtype=np.float64).reshape(-1, A),
+        "move_index": np.array([mv["move"][0] + S * mv["move"][1] if mv["move"][1] != S else S * S for mv in moves], dtype=np.int32),
+        "move_player": np.array([mv["player"] for mv in moves], dtype=np.int8),
+        "move_value": np.array([np.float32(np.asarray(mv["value"]).reshape(-1)[0]) for mv in moves], dtype=np.float32),
+        "move_policy": np.array([mv["policy"] for mv in moves], dtype=np.float64).reshape(-1, A),
+        "move_board_hash": np.array([_sha8(mv["board"]) for mv in moves], dtype=np.uint8).reshape(-1, 8),
+        "result": np.frombuffer(gd["result"].encode(), dtype=np.uint8),
+        "winner": np.array(-99 if gd["winner"] is None else gd["winner"], dtype=np.int32),
+    })
+    for k, v in per_move.items():
+        data["pm_" + k] = np.array(v)
+    np.savez_compressed(out, **data)
+    print("sync S=%d sims=%d batch=%d net=%s: %d moves, result %s" % (size, sims, batch, net_kind, len(moves), gd["result"]))
+
+
 # ----------------------------------------------------------------------------------------------
 # parent side
 # ----------------------------------------------------------------------------------------------
@@ -462,6 +549,14 @@ ASYNC_CASES = [
     (5, 64, 16, "dummy", None, 2, 6),
     (19, 40, 8, "hash", 6, 3, 7),
     (19, 400, 8, "hash", 2, 30, 8),          # the headline search width, two plies
+]
+
+
+SYNC_CASES = [
+    # (size, sims, batch, net, num_moves, stop_exploration, seed)
+    (9, 48, 8, "hash", 10, 4, 11),
+    (9, 32, 4, "dummy", 8, 2, 12),
+    (5, 24, 8, "hash", 12, 3, 13),
 ]
 
 
@@ -488,6 +583,9 @@ def main():
             child_sym(int(a.child[1]), a.child[2])
         elif what == "puct":
             child_puct(a.child[1])
+        elif what == "sync":
+            s_, sims, b, net, nm, se, seed, out = a.child[1:]
+            child_sync(int(s_), int(sims), int(b), net, int(nm), int(se), int(seed), out)
         elif what == "async":
             s, sims, e, net, nm, se, seed, out = a.child[1:]
             child_async(int(s), int(sims), int(e), net, None if nm == "None" else int(nm), int(se), int(seed), out)
@@ -504,6 +602,9 @@ def main():
             run_child(["sym", s, os.path.join(HERE, "sym_S%d.npz" % s)], scratch)
     if only in (None, "puct"):
         run_child(["puct", os.path.join(HERE, "puct.npz")], scratch)
+    if only in (None, "sync"):
+        for i, c in enumerate(SYNC_CASES):
+            run_child(["sync"] + list(c) + [os.path.join(HERE, "sync_%02d.npz" % i)], scratch)
     if only in (None, "async"):
         for i, c in enumerate(ASYNC_CASES):
             run_child(["async"] + list(c) + [os.path.join(HERE, "async_%02d.npz" % i)], scratch)
