@@ -172,6 +172,9 @@ int sgo_game_results(sgo_ctx *ctx, int n, const int32_t *slots, sgo_game_result 
 int sgo_root_table(sgo_ctx *ctx, int slot, int32_t *N, float *W, float *Q, double *P, int8_t *EX, int32_t *root_count,
                    float *root_value);
 int64_t sgo_tree_serialize(sgo_ctx *ctx, int slot, uint8_t *buf, int64_t cap, int64_t *n_nodes, int64_t *n_expanded);
+/* Same walk with 40-byte records <i action, i count, f value, f mean, d p, i vloss, i expanded, i depth, i pad>, from
+ * which a host rebuilds the reference's nested dict nodes (play.py:376-421) -- see engine.SelfPlayEngine.tree_dict. */
+int64_t sgo_tree_dump(sgo_ctx *ctx, int slot, uint8_t *buf, int64_t cap, int64_t *n_nodes);
 int sgo_game_board(sgo_ctx *ctx, int slot, int32_t *board17);
 /* test hook: stop slot right before the move choice of move_n == k (phase becomes done, error 0) */
 int sgo_set_halt(sgo_ctx *ctx, int slot, int move_n);

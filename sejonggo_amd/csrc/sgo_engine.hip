@@ -1006,14 +1006,16 @@ int sgo_root_table(sgo_ctx *x, int slot, int32_t *N, float *W, float *Q, double 
 }
 
 static void ser_rec(const Ctx &c, const Snap &sn, int blk, bool f64, uint8_t *buf, int64_t cap, int64_t &off, int64_t &nn,
-                    int64_t &ne) {
+                    int64_t &ne, int depth = -1) {
+    const int rec = depth >= 0 ? 40 : 32;   // depth >= 0: extended 40-byte records (+ i depth, i pad) for sgo_tree_dump
     for (int a = 0; a < c.A; a++) {
         if (!snap_exists(c, sn, blk, a)) continue;
         const size_t o = (size_t)blk * c.APAD + a;
         const int32_t cb = sn.B[o];
-        if (buf && off + 32 <= cap) {
+        if (buf && off + rec <= cap) {
             int32_t i32;
             double p = f64 ? sn.p64[a] : (double)sn.P[o];
+            if (depth >= 0) { i32 = depth; memcpy(buf + off + 32, &i32, 4); i32 = 0; memcpy(buf + off + 36, &i32, 4); }
             i32 = a; memcpy(buf + off, &i32, 4);
             i32 = sn.N[o]; memcpy(buf + off + 4, &i32, 4);
             memcpy(buf + off + 8, &sn.W[o], 4);
@@ -1022,9 +1024,9 @@ static void ser_rec(const Ctx &c, const Snap &sn, int blk, bool f64, uint8_t *bu
             i32 = sn.busy[o]; memcpy(buf + off + 24, &i32, 4);
             i32 = cb >= 0 ? 1 : 0; memcpy(buf + off + 28, &i32, 4);
         }
-        off += 32;
+        off += rec;
         nn++;
-        if (cb >= 0) { ne++; ser_rec(c, sn, cb, false, buf, cap, off, nn, ne); }
+        if (cb >= 0) { ne++; ser_rec(c, sn, cb, false, buf, cap, off, nn, ne, depth >= 0 ? depth + 1 : -1); }
     }
 }
 
@@ -1039,6 +1041,19 @@ int64_t sgo_tree_serialize(sgo_ctx *x, int slot, uint8_t *buf, int64_t cap, int6
     if (bslot != -2) ser_rec(c, sn, sn.s.root_blk, sn.s.root_f64 != 0, buf, cap, off, nn, ne);
     if (n_nodes) *n_nodes = nn;
     if (n_expanded) *n_expanded = ne;
+    return off;
+}
+
+int64_t sgo_tree_dump(sgo_ctx *x, int slot, uint8_t *buf, int64_t cap, int64_t *n_nodes) {
+    if (!x || slot < 0 || slot >= x->c.G) { set_error("sgo_tree_dump: bad argument"); return SGO_ERR_ARG; }
+    Ctx &c = x->c;
+    Snap sn;
+    CK(snapshot(c, slot, sn));
+    int32_t bslot = 0;
+    SGO_HIP(hipMemcpy(&bslot, c.bSlot + (size_t)slot * c.cap + sn.s.root_blk, sizeof(int32_t), hipMemcpyDeviceToHost));
+    int64_t off = 0, nn = 0, ne = 0;
+    if (bslot != -2) ser_rec(c, sn, sn.s.root_blk, sn.s.root_f64 != 0, buf, cap, off, nn, ne, 0);
+    if (n_nodes) *n_nodes = nn;
     return off;
 }
 

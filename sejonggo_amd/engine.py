@@ -283,6 +283,31 @@ class SelfPlayEngine(object):
                    "sgo_tree_serialize")
         return buf[:sz], nn.value, ne.value
 
+    def tree_dict(self, slot):
+        """The slot's device tree as the reference's nested dict nodes (play.py:376-421: index, count, value,
+        mean_value, p, subtree, parent, virtual_loss) -- a read-only snapshot for inspection, GTP-style front-ends
+        and tests; the search itself never leaves the GPU."""
+        nn = C.c_int64(0)
+        sz = _lib.check(self.lib.sgo_tree_dump(self.ctx, C.c_int(slot), None, C.c_int64(0), C.byref(nn)), "sgo_tree_dump")
+        buf = np.zeros(max(1, sz), dtype=np.uint8)
+        _lib.check(self.lib.sgo_tree_dump(self.ctx, C.c_int(slot), _lib.ptr(buf), C.c_int64(sz), C.byref(nn)), "sgo_tree_dump")
+        recs = np.frombuffer(buf[:sz].tobytes(), dtype=np.dtype([("a", "<i4"), ("n", "<i4"), ("w", "<f4"), ("q", "<f4"),
+                                                                 ("p", "<f8"), ("vl", "<i4"), ("ex", "<i4"), ("d", "<i4"),
+                                                                 ("pad", "<i4")]))
+        t = self.root_table(slot)
+        root = {'index': -1, 'count': int(t["root_count"]), 'value': t["root_value"],
+                'mean_value': (t["root_value"] / np.float32(t["root_count"])) if t["root_count"] else 0, 'p': 1,
+                'subtree': {}, 'parent': None, 'virtual_loss': 0}
+        stack = [root]
+        for r in recs:
+            del stack[int(r["d"]) + 1:]
+            parent = stack[-1]
+            node = {'index': int(r["a"]), 'count': int(r["n"]), 'value': np.float32(r["w"]), 'mean_value': np.float32(r["q"]),
+                    'p': np.float64(r["p"]), 'subtree': {}, 'parent': parent, 'virtual_loss': int(r["vl"])}
+            parent['subtree'][int(r["a"])] = node
+            stack.append(node)
+        return root
+
     def board(self, slot):
         b = np.zeros((1, self.S, self.S, 17), dtype=np.int32)
         _lib.check(self.lib.sgo_game_board(self.ctx, C.c_int(slot), _lib.ptr(b)), "sgo_game_board")

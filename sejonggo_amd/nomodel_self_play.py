@@ -13,9 +13,10 @@ from .predicting_queue_worker import get_model, put_name_request
 
 def play_game_async(model1_indicator, model2_indicator, energy, stop_exploration, process_id, self_play=False,
                     num_moves=None, resign_model1=None, resign_model2=None, seed=None):
-    if model1_indicator != model2_indicator:
-        raise NotImplementedError("two-model evaluation games (evaluate_worker.py:137) are SURVEY.md §8f row 3; "
-                                  "the MI355X engine currently plays single-model self-play games")
+    if model1_indicator != model2_indicator or not self_play:
+        # two different nets / evaluation games: separate tree per player -> the host-tree form of the same loop
+        return play_game_host(model1_indicator, model2_indicator, energy, stop_exploration, process_id, self_play=self_play,
+                              num_moves=num_moves, resign_model1=resign_model1, resign_model2=resign_model2)
     from .engine import SelfPlayEngine
     net = get_model(model1_indicator)
     sym = "random1" if model1_indicator.endswith("_SYM") else "identity"
@@ -37,9 +38,125 @@ def play_game_async(model1_indicator, model2_indicator, energy, stop_exploration
     return gd
 
 
+def _evaluate(model_indicator, boards):
+    """One batched network call for a list of [1,S,S,17] boards -> list of (policy, value)."""
+    from .predicting_queue_worker import predict_batch
+    pol, val = predict_batch(model_indicator, np.concatenate(boards))
+    return [(pol[i], val[i][0]) for i in range(len(boards))]
+
+
+def async_simulate2(node, board, model_indicator, energy, original_player, process_id):
+    """nomodel_self_play.py:59-82 on a host dict tree: pick `energy` distinct leaves by busy-flag exclusion, evaluate
+    them (here: ONE batched forward pass on the GPU instead of a process pool), back-propagate in launch order.
+    When no leaf is selectable the oldest pending result is back-propagated first, as the reference does."""
+    from .play import make_play, index2coord, new_subtree
+    from .tree_util import find_best_leaf_virtual_loss
+    if node['subtree'] == {}:
+        return
+    size = board.shape[-2]
+    pending, done = [], []          # launched leaves awaiting evaluation / evaluated results in launch order
+
+    def flush():
+        if pending:
+            for (leaf, moves, b), (policy, value) in zip(pending, _evaluate(model_indicator, [p[2] for p in pending])):
+                new_leaf = dict(leaf, parent=None)
+                new_leaf['subtree'] = new_subtree(policy, b, new_leaf)
+                v = value if b[0, 0, 0, -1] == original_player else -value
+                new_leaf['count'] += 1
+                new_leaf['value'] += v
+                new_leaf['mean_value'] = new_leaf['value'] / float(new_leaf['count'])
+                done.append((new_leaf, moves))
+            del pending[:]
+
+    pre_bp = 0
+    total = energy
+    while energy > 0:
+        leaf, moves = find_best_leaf_virtual_loss(node)
+        if leaf is not None and leaf['count'] > 0:
+            energy -= 1
+            pre_bp += 1
+            continue
+        if leaf is None:
+            flush()
+            back_propagation(done.pop(0), node)
+            pre_bp += 1
+            continue
+        b = np.copy(board)
+        for m in moves:
+            x, y = index2coord(m, size)
+            make_play(x, y, b)
+        pending.append((leaf, moves, b))
+        energy -= 1
+    flush()
+    for _ in range(total - pre_bp):
+        back_propagation(done.pop(0), node)
+
+
 def select_play(board, energy, mcts_tree, temperature, model_indicator, gpuid):
-    raise NotImplementedError("select_play on a host dict tree is served by the GTP row (SURVEY.md §8f row 4); "
-                              "the device engine owns its trees -- use play_game_async / SelfPlayEngine")
+    """nomodel_self_play.py:114-140 on a host dict tree (GTP-style single-position use)."""
+    for _ in range(int(conf['MCTS_SIMULATIONS'] / conf['ENERGY'])):
+        async_simulate2(mcts_tree, np.copy(board), model_indicator, energy, board[0, 0, 0, -1], gpuid)
+    children = mcts_tree['subtree']
+    if temperature == 1:
+        total_n = sum(c['count'] for c in children.values())
+        moves = [m for m, c in children.items() if c['count']]
+        return np.random.choice(moves, size=1, p=[children[m]['count'] / float(total_n) for m in moves])[0]
+    return max((c['count'], c['mean_value'], a) for a, c in children.items())[2]
+
+
+def play_game_host(model1_indicator, model2_indicator, energy, stop_exploration, process_id, self_play=False, num_moves=None,
+                   resign_model1=None, resign_model2=None):
+    """play_game_async (nomodel_self_play.py:142-271) with host dict trees: the general form that also covers two
+    different models (evaluate_worker.py:137: best vs latest, separate tree per player).  Rules, symmetries and
+    the nets run on the GPU; one game at a time -- throughput self-play uses the device engine instead."""
+    from .play import game_init, make_play, index2coord, get_winner, new_tree
+    from .predicting_queue_worker import put_predict_request
+    size = conf['SIZE']
+    board, player = game_init(size)
+    moves = []
+    current, other = (model1_indicator, model2_indicator) if np.random.random() < .5 else (model2_indicator, model1_indicator)
+    model1_isblack = current == model1_indicator
+    mcts_tree, other_mcts = None, None
+    value, skipped_last, temperature, end_reason = None, False, 1, "PLAYED ALL MOVES"
+    for move_n in range(size * size * 2 if num_moves is None else num_moves):
+        if move_n == stop_exploration:
+            temperature = 0
+        policy, value = put_predict_request(current, board, response_now=True)
+        resign = resign_model1 if current == model1_indicator else resign_model2
+        if resign and value <= resign:
+            end_reason = "resign"
+            break
+        if not mcts_tree or not mcts_tree['subtree']:
+            mcts_tree = new_tree(policy, board, add_noise=self_play)
+            if self_play:
+                other_mcts = mcts_tree
+        index = select_play(board, energy, mcts_tree, temperature, current, process_id)
+        x, y = index2coord(index, size)
+        policy_target = np.zeros(size * size + 1)
+        for a, child in mcts_tree['subtree'].items():
+            policy_target[a] = child['p']
+        moves.append({'board': np.copy(board), 'policy': policy_target, 'value': value, 'move': (x, y), 'move_n': move_n,
+                      'player': player})
+        if skipped_last and y == size:
+            end_reason = "BOTH_PASSED"
+            break
+        skipped_last = y == size
+        if self_play or (other_mcts and index in other_mcts['subtree']):
+            other_mcts = other_mcts['subtree'][index]
+            other_mcts['parent'] = None
+        mcts_tree = mcts_tree['subtree'][index]
+        mcts_tree['parent'] = None
+        board, player = make_play(x, y, board)
+        current, other = other, current
+        mcts_tree, other_mcts = other_mcts, mcts_tree
+    winner, black_points, white_points = get_winner(board)
+    tag = {1: "B", 0: "D", -1: "W"}
+    result = "%s+R" % tag[player] if end_reason == "resign" else "%s+%s" % (tag[winner], abs(black_points - white_points))
+    modelB, modelW = (model1_indicator, model2_indicator) if model1_isblack else (model2_indicator, model1_indicator)
+    nameB, nameW = put_name_request(modelB), put_name_request(modelW)
+    winner_model = None if winner == 0 else (nameB if (winner == 1) == model1_isblack else nameW)
+    return {'moves': moves, 'modelB_name': nameB, 'modelW_name': nameW, 'winner': {1: 1, -1: 0, 0: None}[winner],
+            'winner_model': winner_model, 'result': result, 'resign_model1': resign_model1, 'resign_model2': resign_model2}
 
 
 def back_propagation(result, node):

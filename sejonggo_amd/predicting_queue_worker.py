@@ -78,6 +78,15 @@ def put_predict_request(model_indicator, board, response_now=False):
     return p[0], v[0][0]
 
 
+def predict_batch(model_indicator, boards):
+    """Batched form of put_predict_request for boards [n,S,S,17] -> (policy [n,A] float32, value [n,1] float32)."""
+    from .symmetry import random_symmetry_predict
+    net = get_model(model_indicator)
+    if model_indicator.endswith("_SYM"):
+        return random_symmetry_predict(_NumpyNet(net), np.array(boards))
+    return _NumpyNet(net).predict_on_batch(np.asarray(boards))
+
+
 class _NumpyNet(object):
     def __init__(self, net):
         self.net = net
@@ -85,7 +94,10 @@ class _NumpyNet(object):
 
     def predict_on_batch(self, X):
         import torch
-        p, v = self.net.predict_on_batch(torch.from_numpy(np.ascontiguousarray(X)).cuda() if not torch.is_tensor(X) else X)
+        if getattr(self.net, "numpy_native", False) or not hasattr(self.net, "parameters") and not hasattr(self.net, "device"):
+            p, v = self.net.predict_on_batch(np.ascontiguousarray(X))       # stub nets compute on numpy directly
+        else:
+            p, v = self.net.predict_on_batch(torch.from_numpy(np.ascontiguousarray(X)).cuda() if not torch.is_tensor(X) else X)
         if torch.is_tensor(p):
             p = p.float().cpu().numpy()
             v = v.float().cpu().numpy()

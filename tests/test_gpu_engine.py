@@ -315,3 +315,27 @@ def test_selfplay_worker_body_writes_samples(L, tmp_path):
         pq.destroy_predicting_workers([0])
         conf.clear()
         conf.update(keep)
+
+
+def test_tree_dict_view_equals_the_canonical_serialisation(L):
+    """engine.tree_dict rebuilds the reference's nested dict nodes from the device tree; hashing that dict tree the
+    way the golden harness hashes the reference's dict tree must reproduce the golden hash."""
+    import hashlib
+    from sejonggo_amd.mcts1 import TreeNode
+    from sejonggo_amd.stub_nets import make_stub
+    from tests.helpers import dict_tree_hash
+    z = load("async_02.npz")
+    S = int(z["size"])
+    eng = _engine(z, make_stub("hash", S), halt_at=3)
+    eng.run()
+    tree = eng.tree_dict(0)
+    h, nn = dict_tree_hash(tree)
+    assert nn == z["pm_n_nodes"][3] and h == z["pm_tree_hash"][3].tobytes()
+    assert tree['count'] == z["pm_root_count"][3] and set(tree['subtree']) == set(np.flatnonzero(z["pm_EX"][3]))
+    some = next(iter(tree['subtree'].values()))
+    assert set(some) == {'index', 'count', 'value', 'mean_value', 'p', 'subtree', 'parent', 'virtual_loss'}
+    assert some['parent'] is tree
+    view = TreeNode(tree)
+    assert view.v == tree['count'] and len(view.children) == len(tree['subtree'])
+    assert view.best_move().move == int(np.argmax(z["pm_N"][3]))
+    eng.close()

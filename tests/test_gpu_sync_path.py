@@ -77,3 +77,50 @@ def test_sync_play_game_matches_reference(sync_env, fn, monkeypatch):
         assert np.array_equal(sha8(mv['board']), z["move_board_hash"][i]), i
         assert hashes[i] == z["pm_tree_hash"][i].tobytes(), i
     assert gd['result'] == bytes(z["result"]).decode()
+
+
+@pytest.mark.parametrize("fn", ["async_02.npz", "async_05.npz"])
+def test_host_async_path_matches_reference(sync_env, fn, monkeypatch):
+    """nomodel_self_play.play_game_host (host dict trees, async_simulate2 + back_propagation mirrors) replays the
+    reference's golden async games, including the game that hits the 'No best leaf' path 24 times."""
+    from sejonggo_amd import nomodel_self_play as ns, predicting_queue_worker as pq
+    from sejonggo_amd.stub_nets import make_stub
+    from tests.helpers import dict_tree_hash
+    z = load(fn)
+    S = int(z["size"])
+    nm = int(z["num_moves"])
+    sync_env.update({'SIZE': S, 'MCTS_SIMULATIONS': int(z["sims"]), 'ENERGY': int(z["energy"]), 'KOMI': float(z["komi"])})
+    net = make_stub(bytes(z["net"]).decode(), S)
+    pq.set_model_factory(lambda kind: net)
+    pq.init_predicting_workers([0])
+    uni, noi = list(z["uniforms"]), list(z["noises"])
+
+    def fake_choice(moves, size=1, p=None):
+        cdf = np.cumsum(np.asarray(p, dtype=np.float64))
+        cdf /= cdf[-1]
+        return [moves[int(np.searchsorted(cdf, uni.pop(0), side="right"))]]
+
+    monkeypatch.setattr(np.random, "choice", fake_choice)
+    monkeypatch.setattr(np.random, "dirichlet", lambda alpha: noi.pop(0))
+    hashes = []
+    orig = ns.select_play
+
+    def wrapped(board, energy, tree, temperature, indicator, gpuid):
+        a = orig(board, energy, tree, temperature, indicator, gpuid)
+        hashes.append(dict_tree_hash(tree)[0])
+        return a
+
+    monkeypatch.setattr(ns, "select_play", wrapped)
+    try:
+        gd = ns.play_game_host("BEST_SYM", "BEST_SYM", int(z["energy"]), int(z["stop_exploration"]), 0, self_play=True,
+                               num_moves=None if nm < 0 else nm)
+    finally:
+        pq.set_model_factory(None)
+        pq.destroy_predicting_workers([0])
+    assert len(gd['moves']) == len(z["move_index"])
+    for i, mv in enumerate(gd['moves']):
+        a = mv['move'][0] + S * mv['move'][1] if mv['move'][1] != S else S * S
+        assert a == z["move_index"][i] and mv['player'] == z["move_player"][i], i
+        assert mv['policy'].tobytes() == z["move_policy"][i].tobytes(), i
+        assert hashes[i] == z["pm_tree_hash"][i].tobytes(), i
+    assert gd['result'] == bytes(z["result"]).decode()
