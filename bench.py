@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--channels", type=int, default=256)
     ap.add_argument("--symmetry", default="random1", choices=["random1", "avg8", "identity"])
     ap.add_argument("--net", default="resnet", choices=["resnet", "uniform", "hash"])
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: rehearse the N>1 path on fewer GPUs than ranks (ranks share devices, CPU tensors in the collectives)")
     ap.add_argument("--plain-net", type=int, default=0, help="1: plain PyTorch module instead of the fused inference net")
     ap.add_argument("--saturated", type=int, default=1, help="also time board_advance on a chip-filling dense batch")
     ap.add_argument("--cpu-baseline", type=int, default=1)
@@ -163,8 +165,13 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            local = local % torch.cuda.device_count()
+            torch.cuda.set_device(local)
+            dist.init_process_group("gloo")
     else:
         torch.cuda.set_device(0)
         local = 0
@@ -220,7 +227,7 @@ def main():
         one_step()
     sync()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
