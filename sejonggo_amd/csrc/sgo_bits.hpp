@@ -244,6 +244,35 @@ SGO_DEV void legal_core(const uint32_t (&own)[S], const uint32_t (&opp)[S], cons
             r[y] = opp[y] & ~safe[y];
             anyr |= r[y];
         }
+        // single-stone groups, all at once: a lone stone's liberties are its empty neighbours; exactly one of the
+        // four => that point captures it.  (Bit-sliced "exactly one of U, D, L, R".)
+        {
+            uint32_t fr[S];
+            nbr4<S>(opp, fr);
+            uint32_t anys = 0;
+#pragma unroll
+            for (int y = 0; y < S; y++) anys |= r[y] & ~fr[y];
+            if (anys) {
+                uint32_t s1[S];
+#pragma unroll
+                for (int y = 0; y < S; y++) {
+                    const uint32_t U = (y > 0) ? emp[y - 1] : 0u, D = (y < S - 1) ? emp[y + 1] : 0u;
+                    const uint32_t Lf = (emp[y] << 1) & M, Rt = emp[y] >> 1;
+                    const uint32_t x1 = U ^ D, a1 = U & D, x2 = Lf ^ Rt, a2 = Lf & Rt;
+                    const uint32_t one = (x1 ^ x2) & ~((a1 & x2) | (a2 & x1));
+                    const uint32_t single = r[y] & ~fr[y];
+                    s1[y] = single & one;
+                    r[y] &= ~single;
+                }
+                nbr4<S>(s1, fr);
+                anyr = 0;
+#pragma unroll
+                for (int y = 0; y < S; y++) {
+                    legal[y] |= fr[y] & emp[y];
+                    anyr |= r[y];
+                }
+            }
+        }
         while (anyr) {  // remaining groups: every liberty lies in c; exactly one liberty => capturable there
             uint32_t g[S];
             bool found = false;

@@ -139,12 +139,16 @@ __global__ __launch_bounds__(256) void k_history_shift(int n, const int *n_dev, 
         addr(b2 ? t + 2 * stride : t, s2, d2);
         addr(b3 ? t + 3 * stride : t, s3, d3);
         if constexpr (V4) {
-            uint4 v0 = *reinterpret_cast<const uint4 *>(s0), v1 = *reinterpret_cast<const uint4 *>(s1);
-            uint4 v2 = *reinterpret_cast<const uint4 *>(s2), v3 = *reinterpret_cast<const uint4 *>(s3);
-            *reinterpret_cast<uint4 *>(d0) = v0;
-            if (b1) *reinterpret_cast<uint4 *>(d1) = v1;
-            if (b2) *reinterpret_cast<uint4 *>(d2) = v2;
-            if (b3) *reinterpret_cast<uint4 *>(d3) = v3;
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            // streamed once: non-temporal loads and stores keep the history move out of the L2 working set
+            u32x4 v0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(s0));
+            u32x4 v1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(s1));
+            u32x4 v2 = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(s2));
+            u32x4 v3 = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(s3));
+            __builtin_nontemporal_store(v0, reinterpret_cast<u32x4 *>(d0));
+            if (b1) __builtin_nontemporal_store(v1, reinterpret_cast<u32x4 *>(d1));
+            if (b2) __builtin_nontemporal_store(v2, reinterpret_cast<u32x4 *>(d2));
+            if (b3) __builtin_nontemporal_store(v3, reinterpret_cast<u32x4 *>(d3));
         } else {
             uint32_t v0 = *s0, v1 = *s1, v2 = *s2, v3 = *s3;
             *d0 = v0;
