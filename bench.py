@@ -150,7 +150,7 @@ def saturated_advance(S, n=1 << 18, ply=60, iters=10):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     ach = ALGO_BYTES.get(S, 0) * n / (ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": "board_advance (k_history_shift + k_advance_planes), dense batch", "achieved": ach,
+    return {"bound": "hbm", "kernel": "board_advance, dense batch through sgo_advance_legal_dev (k_history_shift + k_advance_planes)", "achieved": ach,
             "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "positions_per_launch": n, "avg_launch_ms": ms,
             "inputs": "seeded random legal playouts, ply %d" % ply}
 
@@ -254,7 +254,7 @@ def main():
                                       if args.net == "resnet" else args.net + " stub net", args.symmetry),
                        "games_per_gpu": G, "sims": sims, "energy": E, "net_evals_per_position": (sims // E) * E + 1,
                        "sharding": "games g -> rank g mod N; RCCL gather of per-step records to rank 0"},
-            "roofline": {"bound": "hbm", "kernel": "board_advance = k_history_shift + k_advance_planes (make_play + legal set of the new position)",
+            "roofline": {"bound": "hbm", "kernel": "k_board_advance (make_play + legal set of the new position; one launch: register blocks + history-stream blocks)",
                          "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": None, "algorithmic_bytes_per_position": ALGO_BYTES.get(S, 0),
                          "positions_per_launch": per_launch, "avg_launch_ms": avg_ms, "launches": adv_n},

@@ -14,7 +14,8 @@
 //     prefix popcounts.  Games never talk to each other, so there is no inter-workgroup hand-off.
 //   * Per engine step: k_search (consume evaluations -> back-propagate -> select next leaves / play a
 //     move) -> k_compact (prefix sums over games: dense evaluation list + leaf list) -> board_advance
-//     (k_advance_legal, one LANE per leaf) -> [host runs the network on the packed inputs] -> next step.
+//     (k_board_advance, one LANE per leaf + history-stream blocks, sized for the worst case and guarded by the
+//     device-side leaf count so no host round trip sits in between) -> [host runs the network] -> next step.
 //   * Tree storage: every game owns `cap` fixed-size BLOCKS.  A block = one expanded node: its packed
 //     position, legal bitset, and APAD child slots in struct-of-arrays form (P, N, W, Q, child block,
 //     busy) so that the lanes of the selecting wave read consecutive slots (coalesced).  Child slot i
@@ -634,19 +635,6 @@ __global__ __launch_bounds__(1024) void k_compact(Ctx c) {
         d.none_events = c.counters->none_events;
         *c.dstatus = d;
     }
-}
-
-// board_advance over the compacted leaf list; the launch is sized for the worst case and guarded by
-// the device-side count so that no host round trip sits between k_compact and this kernel.
-template <int S>
-__global__ __launch_bounds__(64) void k_leaf_advance(Ctx c) {
-    using G = Geo<S>;
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= c.dstatus->n_leaf) return;
-    const uint32_t *src = c.pos + (size_t)c.leafIn[i] * G::RW;
-    uint32_t *dst = c.pos + (size_t)c.leafOut[i] * G::RW;
-    uint32_t *lg = c.legal + (size_t)c.leafOut[i] * G::NW;
-    advance_record<S>(src, dst, c.leafMv[i], false, lg);
 }
 
 // (re)start listed game slots: empty board in block 0, everything else free

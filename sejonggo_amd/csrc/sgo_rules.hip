@@ -11,6 +11,7 @@
 #include <hip/hip_fp16.h>
 #include <math.h>
 #include <mutex>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -104,15 +105,13 @@ __global__ __launch_bounds__(256) void k_advance_legal(int n, const uint32_t *in
 // reference's shift + pair swap), one thread per 16-B chunk (4-B word when a plane is not a multiple of 16 B):
 // consecutive threads touch consecutive chunks of one record, so every wave instruction covers whole records.
 template <int S>
-__global__ __launch_bounds__(256) void k_history_shift(int n, const int *n_dev, const uint32_t *in, const int32_t *in_idx,
-                                                       const int32_t *colors, uint32_t *out, const int32_t *out_idx) {
+__device__ __forceinline__ void history_shift_body(int n, long t0, long stride, const uint32_t *in, const int32_t *in_idx,
+                                                   const int32_t *colors, uint32_t *out, const int32_t *out_idx) {
     using G = Geo<S>;
     constexpr bool V4 = (G::NW % 4 == 0);
     constexpr int CPP = V4 ? G::NW / 4 : G::NW;   // chunks per plane
     constexpr int CPR = 14 * CPP;                 // chunks per record
-    if (n_dev) n = *n_dev;
     const long total = (long)n * CPR;
-    const long stride = (long)gridDim.x * blockDim.x;
     auto addr = [&](long t, const uint32_t *&sp_, uint32_t *&dp_) {
         const int i = (int)(t / CPR), c = (int)(t - (long)i * CPR);
         const int p = 2 + c / CPP, w = c - (p - 2) * CPP;
@@ -129,7 +128,7 @@ __global__ __launch_bounds__(256) void k_history_shift(int n, const int *n_dev, 
         sp_ = src + sp * G::NW + w * WPC;
         dp_ = dst + p * G::NW + w * WPC;
     };
-    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += 4 * stride) {
+    for (long t = t0; t < total; t += 4 * stride) {
         // four independent chunks in flight per thread
         const uint32_t *s0, *s1, *s2, *s3;
         uint32_t *d0, *d1, *d2, *d3;
@@ -160,6 +159,14 @@ __global__ __launch_bounds__(256) void k_history_shift(int n, const int *n_dev, 
 }
 
 template <int S>
+__global__ __launch_bounds__(256) void k_history_shift(int n, const int *n_dev, const uint32_t *in, const int32_t *in_idx,
+                                                       const int32_t *colors, uint32_t *out, const int32_t *out_idx) {
+    if (n_dev) n = *n_dev;
+    history_shift_body<S>(n, (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x, in, in_idx, colors, out,
+                          out_idx);
+}
+
+template <int S>
 __global__ __launch_bounds__(64) void k_advance_planes(int n, const int *n_dev, const uint32_t *in, const int32_t *in_idx,
                                                        const int32_t *moves, const int32_t *colors, uint32_t *out,
                                                        const int32_t *out_idx, uint32_t *legal, const int32_t *legal_idx,
@@ -167,6 +174,36 @@ __global__ __launch_bounds__(64) void k_advance_planes(int n, const int *n_dev, 
     using G = Geo<S>;
     if (n_dev) n = *n_dev;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t *src = in + (size_t)(in_idx ? in_idx[i] : i) * G::RW;
+    uint32_t *dst = out + (size_t)(out_idx ? out_idx[i] : i) * G::RW;
+    uint32_t *lg = legal ? legal + (size_t)(legal_idx ? legal_idx[i] : i) * G::NW : nullptr;
+    bool swap_first = false;
+    int mover = (src[G::META] & 1u) ? -1 : 1;
+    if (colors) {
+        int c = colors[i];
+        if (c != 0 && c != mover) { swap_first = true; mover = -mover; }
+    }
+    int st = advance_planes<S>(src, dst, moves[i], swap_first, lg);
+    if (status) status[i] = st ? st : mover;
+}
+
+// One launch, two kinds of 64-thread blocks: blocks [0, n_compute_blocks) run the register kernel (one lane per leaf),
+// the rest stream the history planes.  For the engine's small per-step launches this halves the launch latency of
+// board_advance; the two kinds touch disjoint words of the output records.
+template <int S>
+__global__ __launch_bounds__(64) void k_board_advance(int n, const int *n_dev, int n_compute_blocks, const uint32_t *in,
+                                                      const int32_t *in_idx, const int32_t *moves, const int32_t *colors,
+                                                      uint32_t *out, const int32_t *out_idx, uint32_t *legal,
+                                                      const int32_t *legal_idx, int32_t *status) {
+    using G = Geo<S>;
+    if (n_dev) n = *n_dev;
+    if ((int)blockIdx.x >= n_compute_blocks) {
+        const long b = (long)blockIdx.x - n_compute_blocks;
+        history_shift_body<S>(n, b * 64 + threadIdx.x, (long)(gridDim.x - n_compute_blocks) * 64, in, in_idx, colors, out, out_idx);
+        return;
+    }
+    int i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
     const uint32_t *src = in + (size_t)(in_idx ? in_idx[i] : i) * G::RW;
     uint32_t *dst = out + (size_t)(out_idx ? out_idx[i] : i) * G::RW;
@@ -319,18 +356,38 @@ __global__ __launch_bounds__(256) void k_bias_act(long n8, int C8, const half8_t
 // Two launches on the caller's stream: the streaming history move, then the register kernel.  (Running the two
 // on separate streams was measured: they contend for the memory system at low stone density and the fork/join
 // events cost more than the overlap saves at the engine's 8 192-leaf launches.)
+static int adv_mode() {   // SGO_ADV_MODE: 0 two launches, 1 one heterogeneous launch, unset: by batch size
+    static int m = -2;
+    if (m == -2) {
+        const char *e = getenv("SGO_ADV_MODE");
+        m = e ? atoi(e) : -1;
+    }
+    return m;
+}
+
 int launch_advance_split(int S, int n_max, const int *d_n, const uint32_t *d_in, const int32_t *d_in_idx,
                          const int32_t *d_moves, const int32_t *d_colors, uint32_t *d_out, const int32_t *d_out_idx,
                          uint32_t *d_legal, const int32_t *d_legal_idx, int32_t *d_status, hipStream_t st) {
     if (n_max <= 0) return SGO_OK;
+    int mode = adv_mode();
+    if (mode < 0) mode = (n_max <= (1 << 16)) ? 1 : 0;
     SGO_DISPATCH(S, {
         constexpr int CPR = 14 * ((Geo<kS>::NW % 4 == 0) ? Geo<kS>::NW / 4 : Geo<kS>::NW);
-        long blocks = ((long)n_max * CPR + 1023) / 1024;
-        if (blocks > 256 * 16) blocks = 256 * 16;
-        if (blocks < 1) blocks = 1;
-        k_history_shift<kS><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(n_max, d_n, d_in, d_in_idx, d_colors, d_out, d_out_idx);
-        k_advance_planes<kS><<<dim3(cdiv(n_max, 64)), dim3(64), 0, st>>>(n_max, d_n, d_in, d_in_idx, d_moves, d_colors, d_out,
-                                                                         d_out_idx, d_legal, d_legal_idx, d_status);
+        if (mode == 1) {
+            const int nbc = cdiv(n_max, 64);
+            long nbs = ((long)n_max * CPR + 255) / 256;
+            if (nbs > 256 * 32) nbs = 256 * 32;
+            if (nbs < 1) nbs = 1;
+            k_board_advance<kS><<<dim3((unsigned)(nbc + nbs)), dim3(64), 0, st>>>(n_max, d_n, nbc, d_in, d_in_idx, d_moves, d_colors,
+                                                                                 d_out, d_out_idx, d_legal, d_legal_idx, d_status);
+        } else {
+            long blocks = ((long)n_max * CPR + 1023) / 1024;
+            if (blocks > 256 * 16) blocks = 256 * 16;
+            if (blocks < 1) blocks = 1;
+            k_history_shift<kS><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(n_max, d_n, d_in, d_in_idx, d_colors, d_out, d_out_idx);
+            k_advance_planes<kS><<<dim3(cdiv(n_max, 64)), dim3(64), 0, st>>>(n_max, d_n, d_in, d_in_idx, d_moves, d_colors, d_out,
+                                                                             d_out_idx, d_legal, d_legal_idx, d_status);
+        }
     });
     SGO_HIP(hipGetLastError());
     return SGO_OK;

@@ -98,15 +98,17 @@ def run_selfplay(gpu_id, model_indicator="BEST_SYM", n_games=None, games_per_gpu
         return len(start)
 
     played = 0
+    idle = 0          # finished slots that could not be refilled (no game numbers left)
     try:
         active = fill(range(G))
+        idle = G - active
         steps = 0
         while active > 0:
             st = eng.step()
             steps += 1
             if st.n_records >= G:
                 eng.drain()
-            if st.n_done > 0:
+            if st.n_done > idle:
                 eng.drain()
                 res = eng.results()
                 free = []
@@ -126,7 +128,9 @@ def run_selfplay(gpu_id, model_indicator="BEST_SYM", n_games=None, games_per_gpu
                             on_game(g, gd)
                     free.append(s)
                     active -= 1
-                active += fill(free)
+                refilled = fill(free)
+                active += refilled
+                idle += len(free) - refilled
             if max_steps is not None and steps >= max_steps:
                 break
     finally:
