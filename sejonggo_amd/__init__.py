@@ -15,3 +15,6 @@ import os as _os
 _db = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "miopen_db")
 if _os.path.isdir(_db):
     _os.environ.setdefault("MIOPEN_USER_DB_PATH", _db)
+# MIOpen's reference solver (naive_conv, ~1.5 s per call at this batch size) is benchmarked by every Find on a box
+# whose kernel cache is cold; it can never win, so keep it out of the candidate list.
+_os.environ.setdefault("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD", "0")
