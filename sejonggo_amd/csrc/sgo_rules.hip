@@ -298,10 +298,22 @@ __global__ __launch_bounds__(256) void k_nn_pack(int n, const uint32_t *packed, 
         for (int c = 0; c < 17; c++) o[c] = vals[c];
     } else if (layout == 2) {  // NHWC, channels zero-padded to 32 (MFMA-friendly K for the stem convolution)
         T *o = out + ((size_t)e * G::N + pt) * 32;
+        if constexpr (sizeof(T) == 2) {
+            // 64 B per point as four 16-B stores
+            typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+            h8 v[4];
 #pragma unroll
-        for (int c = 0; c < 17; c++) o[c] = vals[c];
+            for (int q = 0; q < 4; q++)
 #pragma unroll
-        for (int c = 17; c < 32; c++) o[c] = (T)0.0f;
+                for (int c = 0; c < 8; c++) v[q][c] = (q * 8 + c < 17) ? (_Float16)(float)vals[q * 8 + c] : (_Float16)0.0f;
+#pragma unroll
+            for (int q = 0; q < 4; q++) reinterpret_cast<h8 *>(o)[q] = v[q];
+        } else {
+#pragma unroll
+            for (int c = 0; c < 17; c++) o[c] = vals[c];
+#pragma unroll
+            for (int c = 17; c < 32; c++) o[c] = (T)0.0f;
+        }
     } else {  // NCHW
         T *o = out + (size_t)e * 17 * G::N + pt;
 #pragma unroll

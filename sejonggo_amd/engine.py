@@ -13,7 +13,6 @@ The net is any object with the reference's model contract (model.py:57,80,90): `
 tensors.  PyTorch is plumbing (device memory, stream, the net itself); the tree and the rules are HIP.
 """
 import ctypes as C
-import math
 import random as pyrandom
 
 import numpy as np
@@ -84,10 +83,8 @@ class SelfPlayEngine(object):
         self.status = _lib.Status()
         self._policy = None
         self._value = None
-        self._sym_k = 0
         self._luts = None
         self.records = {}          # slot -> list of move dicts of the game in progress
-        self.finished = []         # finished game_data dicts
         self.game_ids = {}         # slot -> caller-supplied id
         self.n_steps = 0
         self.n_net_calls = 0
