@@ -77,6 +77,7 @@ def cpu_baseline(args, size, sims, energy, n_blocks, channels, symmetry):
     budget = args.cpu_seconds
     net.predict_on_batch(np.zeros((ng * energy, size, size, 17), np.float32))   # thread-pool / allocator warm-up, untimed
     t0 = time.time()
+    c0 = os.times()
     evals = 0
     ticks = 0
     while any(g.phase != ora.PH_DONE for g in games) and time.time() - t0 < budget:
@@ -101,13 +102,16 @@ def cpu_baseline(args, size, sims, energy, n_blocks, channels, symmetry):
             g.submit(pol[o:o + len(b)], val[o:o + len(b)])
             o += len(b)
     dt = time.time() - t0
+    c1 = os.times()
+    busy = (c1.user - c0.user) + (c1.system - c0.system)
+    used = max(1, int(round(busy / max(dt, 1e-9))))   # cores actually kept busy by this process during the sample
     # positions = completed moves + the completed fraction of the moves in flight (every position costs
     # evals_per_position network evaluations, which is where the CPU time goes)
     positions = evals / float(evals_per_position)
-    return {"value": positions / dt, "unit": "positions/sec", "cores": cores, "kind": "port",
+    return {"value": positions / dt, "unit": "positions/sec", "cores": used, "kind": "port",
             "sample": "%d concurrent games, first %d engine ticks (%d net evals = %.2f positions' worth) in a %.0f s budget; "
-                      "oracle C rules+tree (1 thread) + the same net on torch CPU fp32 (%d threads), %.1f s"
-                      % (ng, ticks, evals, positions, budget, cores, dt)}
+                      "oracle C rules+tree (1 thread) + the same net on torch CPU fp32 (torch threads %d; measured CPU time / wall = "
+                      "%.1f cores), %.1f s" % (ng, ticks, evals, positions, budget, torch.get_num_threads(), busy / max(dt, 1e-9), dt)}
 
 
 def saturated_advance(S, n=1 << 18, ply=60, iters=10):
