@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--channels", type=int, default=256)
     ap.add_argument("--symmetry", default="random1", choices=["random1", "avg8", "identity"])
     ap.add_argument("--net", default="resnet", choices=["resnet", "uniform", "hash"])
+    ap.add_argument("--split-streams", type=int, default=0, help="evaluate the net as two half batches on two streams")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearse the N>1 path on fewer GPUs than ranks (ranks share devices, CPU tensors in the collectives)")
     ap.add_argument("--plain-net", type=int, default=0, help="1: plain PyTorch module instead of the fused inference net")
@@ -189,6 +190,7 @@ def main():
             net = build_net(S, args.blocks, args.channels, name="bench_%db" % args.blocks, seed=0, device="cuda")
         else:
             net, _ = build_fused_net(S, args.blocks, args.channels, name="bench_%db" % args.blocks, seed=0, device="cuda")
+            net.split_streams = bool(args.split_streams)
     else:
         net = make_stub(args.net, S)
     eng = SelfPlayEngine(net, size=S, n_games=G, sims=sims, energy=E, stop_exploration=30, symmetry=args.symmetry,

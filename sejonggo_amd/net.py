@@ -168,6 +168,9 @@ class FusedInferenceNet(object):
         self.v_fc1_w, self.v_fc1_b = f.v_fc1.weight.to(dev, dtype).contiguous(), f.v_fc1.bias.to(dev, dtype).contiguous()
         self.v_fc2_w, self.v_fc2_b = f.v_fc2.weight.to(dev, dtype).contiguous(), f.v_fc2.bias.to(dev, dtype).contiguous()
         self._flops = net.flops_per_eval()
+        self.split_streams = False
+        self.split_min = 1024
+        self._side = None
 
     def flops_per_eval(self):
         return self._flops
@@ -179,15 +182,7 @@ class FusedInferenceNet(object):
                                           torch.cuda.current_stream().cuda_stream), "sgo_bias_act_dev")
         return y
 
-    @torch.no_grad()
-    def predict_on_batch(self, X):
-        """X: [n,S,S,32] fp16 CUDA (channel-padded NHWC) or [n,S,S,17] (padded here)."""
-        if not torch.is_tensor(X):
-            import numpy as np
-            X = torch.from_numpy(np.ascontiguousarray(X))
-        X = X.to(self.device, torch.float16)
-        if X.shape[-1] == 17:
-            X = F.pad(X, (0, 15))
+    def _forward(self, X):
         n = X.shape[0]
         x = X.permute(0, 3, 1, 2)                                 # NCHW view of channels-last memory
         y = self._epilogue(F.conv2d(x, self.stem_w, None, padding=self.stem_pad), self.stem_b)
@@ -202,6 +197,34 @@ class FusedInferenceNet(object):
         p = torch.softmax(F.linear(p, self.p_fc_w, self.p_fc_b).float(), dim=1)
         v = torch.tanh(F.linear(F.relu(F.linear(v, self.v_fc1_w, self.v_fc1_b)), self.v_fc2_w, self.v_fc2_b).float())
         return p, v
+
+    @torch.no_grad()
+    def predict_on_batch(self, X):
+        """X: [n,S,S,32] fp16 CUDA (channel-padded NHWC) or [n,S,S,17] (padded here).
+
+        With `split_streams` the batch is evaluated as two halves on two HIP streams, so that one half's HBM-bound
+        epilogue passes can overlap the other half's MFMA-bound convolutions."""
+        if not torch.is_tensor(X):
+            import numpy as np
+            X = torch.from_numpy(np.ascontiguousarray(X))
+        X = X.to(self.device, torch.float16)
+        if X.shape[-1] == 17:
+            X = F.pad(X, (0, 15))
+        n = X.shape[0]
+        if not self.split_streams or n < 2 * self.split_min or n % 2:
+            return self._forward(X)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        cur = torch.cuda.current_stream()
+        h = n // 2
+        self._side.wait_stream(cur)
+        with torch.cuda.stream(self._side):
+            p1, v1 = self._forward(X[h:])
+        p0, v0 = self._forward(X[:h])
+        cur.wait_stream(self._side)
+        for t in (p1, v1):
+            t.record_stream(cur)
+        return torch.cat([p0, p1]), torch.cat([v0, v1])
 
 
 def build_fused_net(size, n_blocks, channels=256, name="model_0", seed=0, device="cuda"):
