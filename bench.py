@@ -21,7 +21,14 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ALGO_BYTES = {19: 1834, 13: 6 * 4 * 16 * 2 + 8 * 2 + 170, 9: 434, 7: 0, 5: 0}  # SURVEY.md §8d per leaf advance
+def _algo_bytes(size):
+    """packed 2-bit x 8-history state (8*ceil(2N/8) + 8 B meta) read + written, plus the u8 legal mask."""
+    n = size * size
+    rec = 8 * ((2 * n + 7) // 8) + 8
+    return 2 * rec + n + 1
+
+
+ALGO_BYTES = {s: _algo_bytes(s) for s in (5, 7, 9, 13, 19)}   # 19 -> 1834, 9 -> 434
 
 
 def parse():
