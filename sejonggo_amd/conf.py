@@ -29,4 +29,5 @@ conf = {
     'NET_DTYPE': 'fp16',
     'SYMMETRY_MODE': 'random1',  # 'random1' = reference behaviour (symmetry.py:127-132); 'avg8' = 8-fold averaging
     'COMPAT_Z': True,            # reproduce sgfsave.py:56 value_target quirk
+    'WRITE_NPZ_TWIN': True,      # without h5py: keep sample.npz beside the spec-written sample.h5
 }

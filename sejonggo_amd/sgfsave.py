@@ -1,8 +1,10 @@
 """Sample writer with the reference's layout (sgfsave.py:49-79 save_self_play_data):
 SELF_PLAY_DIR/<model>/game_%05d/move_%03d/sample.h5 with datasets board f32 (1,S,S,17), policy_target f32
-(S*S+1), value_target f32 ().  h5py is not installed in this image (probed), so when it is missing the same
-three arrays are written as sample.npz in the same directory (np.load reads them back; `convert_npz_to_h5`
-turns a tree of them into sample.h5 wherever h5py exists).  value_target keeps the reference's rule
+(S*S+1), value_target f32 ().  With h5py the file is written through it, exactly like the reference.  h5py is not
+installed in this image (probed): then sample.h5 is produced by the spec-following minimal writer hdf5_min.py
+(superblock v2 / object header v2; not yet checked against libhdf5) and, while conf['WRITE_NPZ_TWIN'] is set, the
+same three arrays are also stored as sample.npz next to it (`convert_npz_to_h5` re-writes sample.h5 through h5py
+wherever that exists).  value_target keeps the reference's rule
 `1 if winner == player else -1` (sgfsave.py:56) when conf['COMPAT_Z'] is set (default), and the corrected
 outcome-from-mover's-view otherwise."""
 import os
@@ -45,14 +47,18 @@ def save_self_play_data(model_name, game_no, game_data):
                 f.create_dataset('policy_target', data=pol, dtype=np.float32)
                 f.create_dataset('value_target', data=val, dtype=np.float32)
         else:
-            np.savez(os.path.join(directory, 'sample.npz'), board=board, policy_target=pol, value_target=val)
+            from .hdf5_min import write_datasets
+            write_datasets(os.path.join(directory, 'sample.h5'),
+                           {'board': board, 'policy_target': pol, 'value_target': val})
+            if conf.get('WRITE_NPZ_TWIN', True):
+                np.savez(os.path.join(directory, 'sample.npz'), board=board, policy_target=pol, value_target=val)
 
 
 def convert_npz_to_h5(root):
     import h5py
     n = 0
     for d, _, files in os.walk(root):
-        if 'sample.npz' in files and 'sample.h5' not in files:
+        if 'sample.npz' in files:
             z = np.load(os.path.join(d, 'sample.npz'))
             with h5py.File(os.path.join(d, 'sample.h5'), 'w') as f:
                 for k in ('board', 'policy_target', 'value_target'):

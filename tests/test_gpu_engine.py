@@ -308,8 +308,7 @@ def test_selfplay_worker_body_writes_samples(L, tmp_path):
         for g, n in seen:
             d = os.path.join(conf['SELF_PLAY_DIR'], "wk", "game_%05d" % g)
             assert len(os.listdir(d)) == n
-            f = os.path.join(d, "move_000", "sample.h5" if sgfsave.HAVE_H5 else "sample.npz")
-            assert os.path.isfile(f)
+            assert os.path.isfile(os.path.join(d, "move_000", "sample.h5"))
     finally:
         pq.set_model_factory(None)
         pq.destroy_predicting_workers([0])

@@ -66,13 +66,17 @@ def test_sample_writer_layout(tmp_path):
         sgfsave.save_self_play_data("model_0", 7, gd)
         d = os.path.join(str(tmp_path), "model_0", "game_00007", "move_002")
         assert os.path.isdir(d)
+        assert os.path.isfile(os.path.join(d, "sample.h5"))
         if sgfsave.HAVE_H5:
             import h5py
             with h5py.File(os.path.join(d, "sample.h5")) as f:
                 b, p, v = f['board'][:], f['policy_target'][:], f['value_target'][()]
         else:
+            from sejonggo_amd.hdf5_min import read_datasets
+            r = read_datasets(os.path.join(d, "sample.h5"))
+            b, p, v = r['board'], r['policy_target'], r['value_target']
             z = np.load(os.path.join(d, "sample.npz"))
-            b, p, v = z['board'], z['policy_target'], z['value_target']
+            assert np.array_equal(z['board'], b) and np.array_equal(z['policy_target'], p) and z['value_target'] == v
         assert b.shape == (1, S, S, 17) and b.dtype == np.float32
         assert p.shape == (S * S + 1,) and p.dtype == np.float32 and v.dtype == np.float32 and v.shape == () and v == 1
     finally:
@@ -142,3 +146,28 @@ def test_net_contract_and_bn_folding():
     # reference topology: 'valid' stem => tower is (S-2)^2 ; FLOPs as SURVEY.md §8d counts them
     assert PolicyValueNet(19, 20, 256).tower_side == 17
     assert abs(PolicyValueNet(19, 20, 256).flops_per_eval() / 1e9 - 13.66) < 0.01
+
+
+def test_hdf5_min_checksum_and_round_trip(tmp_path):
+    """lookup3 known answers (lookup3.c driver: "Four score and seven years ago") and a write/read round trip; when
+    h5py is importable the spec-written file must also open through libhdf5."""
+    from sejonggo_amd.hdf5_min import lookup3, write_datasets, read_datasets
+    s = b"Four score and seven years ago"
+    assert (lookup3(b""), lookup3(s, 0), lookup3(s, 1)) == (0xdeadbeef, 0x17770551, 0xcd628161)
+    rng = np.random.RandomState(0)
+    want = {'board': rng.randint(-1, 2, size=(1, 19, 19, 17)).astype(np.float32),
+            'policy_target': rng.rand(362).astype(np.float32), 'value_target': np.array(-1, dtype=np.float32)}
+    path = str(tmp_path / "sample.h5")
+    write_datasets(path, want)
+    got = read_datasets(path)
+    assert list(got) == list(want)
+    for k in want:
+        assert got[k].shape == want[k].shape and got[k].dtype == np.float32 and np.array_equal(got[k], want[k])
+    assert open(path, "rb").read(8) == b"\x89HDF\r\n\x1a\n"
+    try:
+        import h5py
+    except Exception:
+        return
+    with h5py.File(path, "r") as f:
+        for k in want:
+            assert np.array_equal(f[k][()], want[k])
