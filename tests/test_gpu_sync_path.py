@@ -124,3 +124,35 @@ def test_host_async_path_matches_reference(sync_env, fn, monkeypatch):
         assert mv['policy'].tobytes() == z["move_policy"][i].tobytes(), i
         assert hashes[i] == z["pm_tree_hash"][i].tobytes(), i
     assert gd['result'] == bytes(z["result"]).decode()
+
+
+def test_gtp_front_end(sync_env):
+    """GTP text loop (sejonggo_nomodel.py:76-185): vertex mapping skips 'I' and counts rows from the bottom; genmove
+    plays a legal move on the engine's board and keeps the searched subtree."""
+    import io
+    from sejonggo_amd import gtp, predicting_queue_worker as pq
+    from sejonggo_amd.play import legal_moves
+    from sejonggo_amd.stub_nets import make_stub
+    sync_env.update({'SIZE': 9, 'MCTS_SIMULATIONS': 32, 'ENERGY': 8, 'GPUs': [0]})
+    net = make_stub("hash", 9)
+    pq.set_model_factory(lambda kind: net)
+    try:
+        e = gtp.GTPEngine()
+        assert e.parse_move("A9") == (0, 0) and e.parse_move("J1") == (8, 8) and e.parse_move("pass") == (0, 9)
+        assert e.print_move(0, 0) == "A9" and e.print_move(8, 8) == "J1" and e.print_move(7, 4) == "H5"
+        assert e.parse_command("protocol_version") == "= 2\n\n" and e.parse_command("boardsize 9") == "=\n\n"
+        assert e.parse_command("play B E5") == "=\n\n" and e.board[0, 4, 4, 1] == 1     # black stone, white to play
+        before = e.board.copy()
+        mask = legal_moves(before)
+        reply = e.parse_command("genmove W")
+        assert reply.startswith("= ") and reply.endswith("\n\n")
+        x, y = e.parse_move(reply[2:].strip())
+        a = 81 if y == 9 else y * 9 + x
+        assert mask[a] == 0 and e.sejong_engine.move == 3
+        assert "name" in e.parse_command("list_commands") and e.parse_command("bogus").startswith("?")
+        out = io.StringIO()
+        gtp.main(io.StringIO("clear_board\ngenmove B\nquit\n"), out)
+        assert out.getvalue().count("=") == 3
+    finally:
+        pq.set_model_factory(None)
+        pq.destroy_predicting_workers([0])
