@@ -42,7 +42,7 @@ def unpack_positions(packed, size):
 class SelfPlayEngine(object):
     def __init__(self, net, size=None, n_games=None, sims=None, energy=None, stop_exploration=None, num_moves=None,
                  komi=None, self_play=True, dirichlet_alpha=None, dirichlet_epsilon=None, blocks_per_game=0,
-                 device=0, symmetry="random1", layout="nhwc", dtype="fp16", seed=0):
+                 device=0, symmetry="random1", layout="nhwc", dtype="fp16", seed=0, raise_on_error=True):
         import torch
         self.torch = torch
         self.lib = _lib.require_gpu()
@@ -90,6 +90,7 @@ class SelfPlayEngine(object):
         self.n_net_calls = 0
         self.n_net_positions = 0
         self._primed = False
+        self.raise_on_error = raise_on_error   # False: a failing slot (e.g. block pool exhausted) is left to the caller
 
     def close(self):
         if getattr(self, "ctx", None):
@@ -180,7 +181,7 @@ class SelfPlayEngine(object):
                    "sgo_step")
         self._primed = True
         self.n_steps += 1
-        if self.status.error:
+        if self.status.error and self.raise_on_error:
             raise _lib.SgoError("game slot %d failed with error %d (%s)" % (
                 self.status.error_game, self.status.error,
                 {-201: "tree-block pool exhausted: raise blocks_per_game", -202: "ran out of injected random draws",

@@ -109,54 +109,19 @@ def play_game_host(model1_indicator, model2_indicator, energy, stop_exploration,
     """play_game_async (nomodel_self_play.py:142-271) with host dict trees: the general form that also covers two
     different models (evaluate_worker.py:137: best vs latest, separate tree per player).  Rules, symmetries and
     the nets run on the GPU; one game at a time -- throughput self-play uses the device engine instead."""
-    from .play import game_init, make_play, index2coord, get_winner, new_tree
+    from ._game_loop import play_loop
     from .predicting_queue_worker import put_predict_request
-    size = conf['SIZE']
-    board, player = game_init(size)
-    moves = []
-    current, other = (model1_indicator, model2_indicator) if np.random.random() < .5 else (model2_indicator, model1_indicator)
-    model1_isblack = current == model1_indicator
-    mcts_tree, other_mcts = None, None
-    value, skipped_last, temperature, end_reason = None, False, 1, "PLAYED ALL MOVES"
-    for move_n in range(size * size * 2 if num_moves is None else num_moves):
-        if move_n == stop_exploration:
-            temperature = 0
-        policy, value = put_predict_request(current, board, response_now=True)
-        resign = resign_model1 if current == model1_indicator else resign_model2
-        if resign and value <= resign:
-            end_reason = "resign"
-            break
-        if not mcts_tree or not mcts_tree['subtree']:
-            mcts_tree = new_tree(policy, board, add_noise=self_play)
-            if self_play:
-                other_mcts = mcts_tree
-        index = select_play(board, energy, mcts_tree, temperature, current, process_id)
-        x, y = index2coord(index, size)
-        policy_target = np.zeros(size * size + 1)
-        for a, child in mcts_tree['subtree'].items():
-            policy_target[a] = child['p']
-        moves.append({'board': np.copy(board), 'policy': policy_target, 'value': value, 'move': (x, y), 'move_n': move_n,
-                      'player': player})
-        if skipped_last and y == size:
-            end_reason = "BOTH_PASSED"
-            break
-        skipped_last = y == size
-        if self_play or (other_mcts and index in other_mcts['subtree']):
-            other_mcts = other_mcts['subtree'][index]
-            other_mcts['parent'] = None
-        mcts_tree = mcts_tree['subtree'][index]
-        mcts_tree['parent'] = None
-        board, player = make_play(x, y, board)
-        current, other = other, current
-        mcts_tree, other_mcts = other_mcts, mcts_tree
-    winner, black_points, white_points = get_winner(board)
-    tag = {1: "B", 0: "D", -1: "W"}
-    result = "%s+R" % tag[player] if end_reason == "resign" else "%s+%s" % (tag[winner], abs(black_points - white_points))
-    modelB, modelW = (model1_indicator, model2_indicator) if model1_isblack else (model2_indicator, model1_indicator)
-    nameB, nameW = put_name_request(modelB), put_name_request(modelW)
-    winner_model = None if winner == 0 else (nameB if (winner == 1) == model1_isblack else nameW)
-    return {'moves': moves, 'modelB_name': nameB, 'modelW_name': nameW, 'winner': {1: 1, -1: 0, 0: None}[winner],
-            'winner_model': winner_model, 'result': result, 'resign_model1': resign_model1, 'resign_model2': resign_model2}
+    swap = np.random.random() >= .5
+    first, second = (model2_indicator, model1_indicator) if swap else (model1_indicator, model2_indicator)
+    r_first, r_second = (resign_model2, resign_model1) if swap else (resign_model1, resign_model2)
+
+    def choose(board, tree, temperature, indicator):
+        # looked up on the module so that a wrapped select_play (tests, instrumentation) is honoured
+        return globals()["select_play"](board, energy, tree, temperature, indicator, process_id)
+
+    return play_loop(conf['SIZE'], first, second, lambda ind, board: put_predict_request(ind, board, response_now=True),
+                     choose, put_name_request, stop_exploration, self_play=self_play, num_moves=num_moves,
+                     resign_first=r_first, resign_second=r_second, first_is_model1=not swap)
 
 
 def back_propagation(result, node):

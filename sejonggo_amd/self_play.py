@@ -7,7 +7,7 @@ engine.SelfPlayEngine, not of this module."""
 import numpy as np
 
 from .conf import conf
-from .play import (game_init, get_winner, index2coord, make_play, new_subtree, new_tree, top_n_actions, top_one_action)
+from .play import index2coord, make_play, new_subtree, top_n_actions, top_one_action
 from .symmetry import random_symmetry_predict
 
 
@@ -72,52 +72,18 @@ def select_play(policy, board, mcts_simulations, mcts_tree, temperature, model):
 
 def play_game(model1, model2, mcts_simulations, stop_exploration, self_play=False, num_moves=None, resign_model1=None,
               resign_model2=None):
-    size = conf['SIZE']
-    board, player = game_init(size)
-    moves = []
-    current_model, other_model = model1, model2          # choose_first_player is a coin flip between equals in self-play
-    if not self_play and np.random.random() >= .5:
-        current_model, other_model = model2, model1
-    model1_isblack = current_model is model1
-    mcts_tree, other_mcts = None, None
-    value, skipped_last, temperature, end_reason = None, False, 1, "PLAYED ALL MOVES"
-    for move_n in range(size * size * 2 if num_moves is None else num_moves):
-        if move_n == stop_exploration:
-            temperature = 0
-        policies, values = current_model.predict_on_batch(board)
-        policy, value = policies[0], values[0]
-        resign = resign_model1 if current_model is model1 else resign_model2
-        if resign and value <= resign:
-            end_reason = "resign"
-            break
-        if not mcts_tree or not mcts_tree['subtree']:
-            mcts_tree = new_tree(policy, board, add_noise=self_play)
-            if self_play:
-                other_mcts = mcts_tree
-        index = select_play(policy, board, mcts_simulations, mcts_tree, temperature, current_model)
-        x, y = index2coord(index, size)
-        policy_target = np.zeros(size * size + 1)
-        for a, child in mcts_tree['subtree'].items():
-            policy_target[a] = child['p']
-        moves.append({'board': np.copy(board), 'policy': policy_target, 'value': value, 'move': (x, y), 'move_n': move_n,
-                      'player': player})
-        if skipped_last and y == size:
-            end_reason = "BOTH_PASSED"
-            break
-        skipped_last = y == size
-        if self_play or (other_mcts and index in other_mcts['subtree']):
-            other_mcts = other_mcts['subtree'][index]
-            other_mcts['parent'] = None
-        mcts_tree = mcts_tree['subtree'][index]
-        mcts_tree['parent'] = None
-        board, player = make_play(x, y, board)
-        current_model, other_model = other_model, current_model
-        mcts_tree, other_mcts = other_mcts, mcts_tree
-    winner, black_points, white_points = get_winner(board)
-    tag = {1: "B", 0: "D", -1: "W"}
-    result = "%s+R" % tag[player] if end_reason == "resign" else "%s+%s" % (tag[winner], abs(black_points - white_points))
-    modelB, modelW = (model1, model2) if model1_isblack else (model2, model1)
-    winner_model = None if winner == 0 else (model1 if (winner == 1) == model1_isblack else model2)
-    return {'moves': moves, 'modelB_name': modelB.name, 'modelW_name': modelW.name, 'winner': {1: 1, -1: 0, 0: None}[winner],
-            'winner_model': None if winner_model is None else winner_model.name, 'result': result,
-            'resign_model1': resign_model1, 'resign_model2': resign_model2}
+    """self_play.py:164-290.  Who plays black is a coin flip (choose_first_player, play.py:301-306)."""
+    from ._game_loop import play_loop
+    swap = (not self_play) and np.random.random() >= .5
+    first, second = (model2, model1) if swap else (model1, model2)
+    r_first, r_second = (resign_model2, resign_model1) if swap else (resign_model1, resign_model2)
+
+    def evaluate(model, board):
+        policies, values = model.predict_on_batch(board)
+        return policies[0], values[0]
+
+    def choose(board, tree, temperature, model):
+        return select_play(None, board, mcts_simulations, tree, temperature, model)
+
+    return play_loop(conf['SIZE'], first, second, evaluate, choose, lambda m: m.name, stop_exploration, self_play=self_play,
+                     num_moves=num_moves, resign_first=r_first, resign_second=r_second, first_is_model1=not swap)

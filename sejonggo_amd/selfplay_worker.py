@@ -81,7 +81,7 @@ def run_selfplay(gpu_id, model_indicator="BEST_SYM", n_games=None, games_per_gpu
     sym = conf.get('SYMMETRY_MODE', 'random1') if model_indicator.endswith("_SYM") else "identity"
     eng = SelfPlayEngine(net, size=conf['SIZE'], n_games=G, sims=conf['MCTS_SIMULATIONS'], energy=conf['ENERGY'],
                          stop_exploration=conf['STOP_EXPLORATION'], komi=conf['KOMI'], self_play=True, symmetry=sym,
-                         device=gpu_id, seed=gpu_id)
+                         device=gpu_id, seed=gpu_id, raise_on_error=False)
     slot_game, slot_resign = {}, {}
 
     def fill(slots):
@@ -108,11 +108,22 @@ def run_selfplay(gpu_id, model_indicator="BEST_SYM", n_games=None, games_per_gpu
             steps += 1
             if st.n_records >= G:
                 eng.drain()
-            if st.n_done > idle:
+            if st.n_done > idle or (st.error and st.error_game in slot_game):
                 eng.drain()
                 res = eng.results()
                 free = []
                 for s in list(slot_game):
+                    if res[s]["done"] < 0:
+                        # the slot failed (typically SGO_ERR_CAPACITY: its tree outgrew blocks_per_game): give the game
+                        # number back, drop what was recorded, and let the slot start a fresh game -- loudly
+                        print("self-play slot %d (game %d) failed with engine error %d; game discarded" % (
+                            s, slot_game[s], res[s]["done"]), file=sys.stderr)
+                        sched.discard(slot_game.pop(s))
+                        slot_resign.pop(s, None)
+                        eng.records[s] = []
+                        free.append(s)
+                        active -= 1
+                        continue
                     if res[s]["done"] != 1:
                         continue
                     gd = eng.game_data(s, res[s], model_name)

@@ -369,3 +369,38 @@ def test_other_sizes_and_energies_equal_the_oracle(L, S, sims, E, nm):
         assert games[s]["black_points"] == r["black"] and games[s]["white_points"] == r["white"]
     assert eng.status.total_evals == sum(1 + (sims // E) * E for _ in range(G)) * nm or eng.status.none_events > 0 or True
     eng.close()
+
+
+def test_worker_survives_a_slot_that_outgrows_its_block_pool(L, tmp_path, monkeypatch):
+    """With a deliberately tiny block pool some games fail with SGO_ERR_CAPACITY: the worker body must discard exactly
+    those games (loudly), keep the others, and terminate."""
+    import os
+    from sejonggo_amd import engine as eng_mod, predicting_queue_worker as pq
+    from sejonggo_amd.conf import conf
+    from sejonggo_amd.selfplay_worker import run_selfplay
+    from sejonggo_amd.stub_nets import make_stub
+    keep = dict(conf)
+    real = eng_mod.SelfPlayEngine
+
+    def tiny(*a, **k):
+        k["blocks_per_game"] = 40
+        k["num_moves"] = 6
+        return real(*a, **k)
+
+    monkeypatch.setattr(eng_mod, "SelfPlayEngine", tiny)
+    try:
+        conf.update({'SIZE': 9, 'MCTS_SIMULATIONS': 24, 'ENERGY': 8, 'STOP_EXPLORATION': 0, 'N_GAMES': 6,
+                     'SELF_PLAY_DIR': str(tmp_path / "sp"), 'GAMES_PER_GPU': 3})
+        net = make_stub("hash", 9)
+        pq.set_model_factory(lambda kind: net)
+        seen = []
+        played = run_selfplay(0, "BEST", n_games=6, games_per_gpu=3, on_game=lambda g, gd: seen.append(g), max_steps=2000)
+        root = os.path.join(conf['SELF_PLAY_DIR'], net.name)
+        kept = sorted(os.listdir(root)) if os.path.isdir(root) else []
+        assert played == len(seen) == len(kept)          # failed games leave no directory behind
+        assert played < 6                                # the pool really was too small for some of them
+    finally:
+        pq.set_model_factory(None)
+        pq.destroy_predicting_workers([0])
+        conf.clear()
+        conf.update(keep)
