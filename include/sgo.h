@@ -95,6 +95,12 @@ int sgo_nn_pack_dev(int S, int n, const uint32_t *d_packed, const int32_t *d_idx
 int sgo_bias_act_dev(long n_elems, int channels, const void *d_x, const void *d_bias, const void *d_skip, void *d_out,
                      void *stream);
 
+/* The tower convolution of the resident net with the epilogue fused: y = relu(conv3x3(x, w) + bias[k] (+ skip)),
+ * stride 1, pad 0 or 1, NHWC fp16 (x [n][h][w][c], w [k][3][3][c] = PyTorch channels_last weight storage,
+ * y / skip [n][ho][wo][k]), fp32 accumulation on MFMA.  c and k must be multiples of 8. */
+int sgo_conv3x3_bias_act_dev(int n, int h, int w, int c, int k, int pad, const void *d_x, const void *d_w,
+                             const void *d_bias, const void *d_skip, void *d_y, void *stream);
+
 /* ---- self-play engine: virtual-loss PUCT + game loop, many games resident on one GPU ------------ */
 /* Replaces nomodel_self_play.py:59-82 async_simulate2, :114-140 select_play, :142-271 play_game_async,
  * tree_util.py:4-32, play.py:308-323/376-421, simulation_workers.py:42-54 basic_tasks2 and the request

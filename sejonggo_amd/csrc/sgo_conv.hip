@@ -1,0 +1,91 @@
+// sgo_conv.hip -- the residual tower's 3x3 convolution with the bias / skip / ReLU epilogue fused into the GEMM's
+// output stage, for the resident policy/value net (model.py:37-46 of the reference: Conv2D -> BatchNorm (folded) ->
+// [Add] -> ReLU).  The implicit-GEMM main loop is AMD's composable_kernel xdlops (MFMA) grouped-convolution template,
+// instantiated here with the tile shape MIOpen's tuner selects for this problem on gfx950
+// (256 threads, 256x128x32 tile, 32x32 MFMA, 4x2 waves-tiles) and with OUR epilogue functors, so that the separate
+// bias/skip/ReLU pass over the 1.2 GB activation tensor disappears.  NHWC fp16 in, fp16 out, fp32 accumulate.
+#include <array>
+
+#include "ck/ck.hpp"
+#include "ck/tensor_operation/gpu/device/convolution_forward_specialization.hpp"
+#include "ck/tensor_operation/gpu/device/gemm_specialization.hpp"
+#include "ck/tensor_operation/gpu/device/impl/device_grouped_conv_fwd_multiple_abd_xdl_cshuffle.hpp"
+#include "ck/tensor_operation/gpu/device/tensor_layout.hpp"
+#include "ck/tensor_operation/gpu/element/element_wise_operation.hpp"
+
+#include "sgo_common.hpp"
+
+namespace {
+
+using F16 = ck::half_t;
+using F32 = float;
+template <ck::index_t... Is>
+using S = ck::Sequence<Is...>;
+using PassThrough = ck::tensor_operation::element_wise::PassThrough;
+namespace lay = ck::tensor_layout::convolution;
+
+// e = relu(conv + bias[k])
+struct BiasRelu {
+    template <typename E, typename C, typename D0>
+    __host__ __device__ constexpr void operator()(E &e, const C &c, const D0 &bias) const {
+        const float x = ck::type_convert<float>(c) + ck::type_convert<float>(bias);
+        e = ck::type_convert<E>(x > 0.f ? x : 0.f);
+    }
+};
+// e = relu(conv + bias[k] + skip)
+struct BiasAddRelu {
+    template <typename E, typename C, typename D0, typename D1>
+    __host__ __device__ constexpr void operator()(E &e, const C &c, const D0 &bias, const D1 &skip) const {
+        const float x = ck::type_convert<float>(c) + ck::type_convert<float>(bias) + ck::type_convert<float>(skip);
+        e = ck::type_convert<E>(x > 0.f ? x : 0.f);
+    }
+};
+
+template <typename DsLayout, typename DsTypes, typename Op>
+using Conv = ck::tensor_operation::device::DeviceGroupedConvFwdMultipleABD_Xdl_CShuffle<
+    2, lay::NHWGC, lay::GKYXC, DsLayout, lay::NHWGK, F16, F16, F32, F16, DsTypes, F16, PassThrough, PassThrough, Op,
+    ck::tensor_operation::device::ConvolutionForwardSpecialization::Default,
+    ck::tensor_operation::device::GemmSpecialization::MNKPadding, 1, 256, 256, 128, 32, 8, 8, 32, 32, 4, 2, S<4, 64, 1>,
+    S<1, 0, 2>, S<1, 0, 2>, 2, 8, 8, 1, S<4, 64, 1>, S<1, 0, 2>, S<1, 0, 2>, 2, 8, 8, 1, 1, 1, S<1, 32, 1, 8>, 8>;
+
+using ConvBias = Conv<ck::Tuple<lay::G_K>, ck::Tuple<F16>, BiasRelu>;
+using ConvBiasSkip = Conv<ck::Tuple<lay::G_K, lay::NHWGK>, ck::Tuple<F16, F16>, BiasAddRelu>;
+
+using Arr5 = std::array<ck::index_t, 5>;
+
+}  // namespace
+
+extern "C" int sgo_conv3x3_bias_act_dev(int n, int h, int w, int c, int k, int pad, const void *d_x, const void *d_w,
+                                        const void *d_bias, const void *d_skip, void *d_y, void *stream) {
+    using namespace sgo;
+    if (n <= 0 || h <= 0 || w <= 0 || c <= 0 || k <= 0 || pad < 0 || pad > 1 || c % 8 || k % 8 || !d_x || !d_w || !d_bias || !d_y) {
+        set_error("sgo_conv3x3_bias_act_dev: bad argument (channels must be multiples of 8)");
+        return SGO_ERR_ARG;
+    }
+    const int ho = h + 2 * pad - 2, wo = w + 2 * pad - 2;
+    if (ho <= 0 || wo <= 0) { set_error("sgo_conv3x3_bias_act_dev: empty output"); return SGO_ERR_ARG; }
+    // [G, N, C, Hi, Wi] lengths with NHWGC strides (G = 1)
+    const Arr5 a_len{1, n, c, h, w}, a_str{c, h * w * c, 1, w * c, c};
+    const Arr5 b_len{1, k, c, 3, 3}, b_str{k * 9 * c, 9 * c, 1, 3 * c, c};
+    const Arr5 e_len{1, n, k, ho, wo}, e_str{k, ho * wo * k, 1, wo * k, k};
+    const Arr5 bias_str{k, 0, 1, 0, 0};
+    const std::array<ck::index_t, 2> ones{1, 1}, pads{pad, pad};
+    const StreamConfig cfg{(hipStream_t)stream, false};
+    if (d_skip) {
+        ConvBiasSkip op;
+        auto arg = op.MakeArgument(d_x, d_w, std::array<const void *, 2>{d_bias, d_skip}, d_y, a_len, a_str, b_len, b_str,
+                                   std::array<Arr5, 2>{e_len, e_len}, std::array<Arr5, 2>{bias_str, e_str}, e_len, e_str, ones,
+                                   ones, pads, pads, PassThrough{}, PassThrough{}, BiasAddRelu{});
+        if (!op.IsSupportedArgument(arg)) { set_error("sgo_conv3x3_bias_act_dev: shape not supported by the instance"); return SGO_ERR_ARG; }
+        op.MakeInvoker().Run(arg, cfg);
+    } else {
+        ConvBias op;
+        auto arg = op.MakeArgument(d_x, d_w, std::array<const void *, 1>{d_bias}, d_y, a_len, a_str, b_len, b_str,
+                                   std::array<Arr5, 1>{e_len}, std::array<Arr5, 1>{bias_str}, e_len, e_str, ones, ones, pads, pads,
+                                   PassThrough{}, PassThrough{}, BiasRelu{});
+        if (!op.IsSupportedArgument(arg)) { set_error("sgo_conv3x3_bias_act_dev: shape not supported by the instance"); return SGO_ERR_ARG; }
+        op.MakeInvoker().Run(arg, cfg);
+    }
+    SGO_HIP(hipGetLastError());
+    return SGO_OK;
+}

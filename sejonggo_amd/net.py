@@ -169,6 +169,7 @@ class FusedInferenceNet(object):
         self.v_fc2_w, self.v_fc2_b = f.v_fc2.weight.to(dev, dtype).contiguous(), f.v_fc2.bias.to(dev, dtype).contiguous()
         self._flops = net.flops_per_eval()
         self.split_streams = False
+        self.fused_conv = True     # conv + bias + skip + ReLU in one MFMA kernel (sgo_conv.hip); False: MIOpen + k_bias_act
         self.split_min = 1024
         self._side = None
 
@@ -182,13 +183,27 @@ class FusedInferenceNet(object):
                                           torch.cuda.current_stream().cuda_stream), "sgo_bias_act_dev")
         return y
 
+    def _conv(self, x, w, b, pad, skip=None):
+        """relu(conv3x3(x, w) + b (+ skip)) on NCHW views of channels-last tensors."""
+        if not self.fused_conv:
+            return self._epilogue(F.conv2d(x, w, None, padding=pad), b, skip=skip)
+        n, c, h, wd = x.shape
+        k = w.shape[0]
+        y = torch.empty((n, k, h + 2 * pad - 2, wd + 2 * pad - 2), dtype=x.dtype, device=x.device,
+                        memory_format=torch.channels_last)
+        self._lib.check(self.lib.sgo_conv3x3_bias_act_dev(n, h, wd, c, k, pad, x.data_ptr(), w.data_ptr(), b.data_ptr(),
+                                                          None if skip is None else skip.data_ptr(), y.data_ptr(),
+                                                          torch.cuda.current_stream().cuda_stream), "sgo_conv3x3_bias_act_dev")
+        return y
+
     def _forward(self, X):
         n = X.shape[0]
         x = X.permute(0, 3, 1, 2)                                 # NCHW view of channels-last memory
-        y = self._epilogue(F.conv2d(x, self.stem_w, None, padding=self.stem_pad), self.stem_b)
+        pad0 = self.stem_pad[0] if isinstance(self.stem_pad, (tuple, list)) else self.stem_pad
+        y = self._conv(x, self.stem_w, self.stem_b, pad0)
         for (w1, b1, w2, b2) in self.blocks:
-            z = self._epilogue(F.conv2d(y, w1, None, padding=1), b1)
-            y = self._epilogue(F.conv2d(z, w2, None, padding=1), b2, skip=y)
+            z = self._conv(y, w1, b1, 1)
+            y = self._conv(z, w2, b2, 1, skip=y)
         t2 = self.t * self.t
         h = F.relu(F.linear(y.permute(0, 2, 3, 1).reshape(n * t2, self.channels), self.head_w, self.head_b))
         h = h.reshape(n, t2, 4)

@@ -404,3 +404,28 @@ def test_worker_survives_a_slot_that_outgrows_its_block_pool(L, tmp_path, monkey
         pq.destroy_predicting_workers([0])
         conf.clear()
         conf.update(keep)
+
+
+def test_fused_conv_kernel_matches_torch(L):
+    """sgo_conv3x3_bias_act_dev (MFMA implicit GEMM with our bias/skip/ReLU epilogue) against torch conv2d in fp32."""
+    import torch
+    import torch.nn.functional as F
+    lib = L.load()
+    torch.manual_seed(0)
+    for (n, h, c, k, pad, with_skip) in [(8, 17, 256, 256, 1, True), (8, 17, 256, 256, 1, False), (5, 19, 32, 256, 0, False),
+                                         (3, 7, 64, 64, 1, True), (300, 17, 256, 256, 1, True)]:
+        x = (torch.randn(n, c, h, h, device="cuda") * 0.5).half().contiguous(memory_format=torch.channels_last)
+        w = (torch.randn(k, c, 3, 3, device="cuda") * 0.03).half().contiguous(memory_format=torch.channels_last)
+        b = torch.randn(k, device="cuda").half()
+        ho = h + 2 * pad - 2
+        skip = (torch.randn(n, k, ho, ho, device="cuda")).half().contiguous(memory_format=torch.channels_last) if with_skip else None
+        y = torch.empty((n, k, ho, ho), dtype=torch.float16, device="cuda", memory_format=torch.channels_last)
+        L.check(lib.sgo_conv3x3_bias_act_dev(n, h, h, c, k, pad, x.data_ptr(), w.data_ptr(), b.data_ptr(),
+                                             None if skip is None else skip.data_ptr(), y.data_ptr(),
+                                             torch.cuda.current_stream().cuda_stream))
+        ref = F.conv2d(x.float(), w.float(), b.float(), padding=pad)
+        if with_skip:
+            ref = ref + skip.float()
+        ref = torch.relu(ref)
+        err = float((y.float() - ref).abs().max())
+        assert err <= 2e-2 * max(1.0, float(ref.abs().max())), (n, h, c, k, pad, with_skip, err)
