@@ -64,27 +64,38 @@ extern "C" int sgo_conv3x3_bias_act_dev(int n, int h, int w, int c, int k, int p
     }
     const int ho = h + 2 * pad - 2, wo = w + 2 * pad - 2;
     if (ho <= 0 || wo <= 0) { set_error("sgo_conv3x3_bias_act_dev: empty output"); return SGO_ERR_ARG; }
-    // [G, N, C, Hi, Wi] lengths with NHWGC strides (G = 1)
-    const Arr5 a_len{1, n, c, h, w}, a_str{c, h * w * c, 1, w * c, c};
-    const Arr5 b_len{1, k, c, 3, 3}, b_str{k * 9 * c, 9 * c, 1, 3 * c, c};
-    const Arr5 e_len{1, n, k, ho, wo}, e_str{k, ho * wo * k, 1, wo * k, k};
-    const Arr5 bias_str{k, 0, 1, 0, 0};
+    // the instance addresses tensors with 32-bit element offsets: run batches whose tensors exceed 2^31 bytes in slices
+    const long per_in = (long)h * w * c * 2, per_out = (long)ho * wo * k * 2;
+    long max_n = ((1L << 31) - 1) / (per_in > per_out ? per_in : per_out);
+    if (max_n > 256) max_n -= max_n % 256;
+    if (max_n < 1) { set_error("sgo_conv3x3_bias_act_dev: one sample exceeds the addressable range"); return SGO_ERR_ARG; }
     const std::array<ck::index_t, 2> ones{1, 1}, pads{pad, pad};
     const StreamConfig cfg{(hipStream_t)stream, false};
-    if (d_skip) {
-        ConvBiasSkip op;
-        auto arg = op.MakeArgument(d_x, d_w, std::array<const void *, 2>{d_bias, d_skip}, d_y, a_len, a_str, b_len, b_str,
-                                   std::array<Arr5, 2>{e_len, e_len}, std::array<Arr5, 2>{bias_str, e_str}, e_len, e_str, ones,
-                                   ones, pads, pads, PassThrough{}, PassThrough{}, BiasAddRelu{});
-        if (!op.IsSupportedArgument(arg)) { set_error("sgo_conv3x3_bias_act_dev: shape not supported by the instance"); return SGO_ERR_ARG; }
-        op.MakeInvoker().Run(arg, cfg);
-    } else {
-        ConvBias op;
-        auto arg = op.MakeArgument(d_x, d_w, std::array<const void *, 1>{d_bias}, d_y, a_len, a_str, b_len, b_str,
-                                   std::array<Arr5, 1>{e_len}, std::array<Arr5, 1>{bias_str}, e_len, e_str, ones, ones, pads, pads,
-                                   PassThrough{}, PassThrough{}, BiasRelu{});
-        if (!op.IsSupportedArgument(arg)) { set_error("sgo_conv3x3_bias_act_dev: shape not supported by the instance"); return SGO_ERR_ARG; }
-        op.MakeInvoker().Run(arg, cfg);
+    for (long n0 = 0; n0 < n; n0 += max_n) {
+        const int nn = (int)((n - n0 < max_n) ? (n - n0) : max_n);
+        const char *x0 = (const char *)d_x + n0 * per_in;
+        const char *s0 = d_skip ? (const char *)d_skip + n0 * per_out : nullptr;
+        char *y0 = (char *)d_y + n0 * per_out;
+        // [G, N, C, Hi, Wi] lengths with NHWGC strides (G = 1)
+        const Arr5 a_len{1, nn, c, h, w}, a_str{c, h * w * c, 1, w * c, c};
+        const Arr5 b_len{1, k, c, 3, 3}, b_str{k * 9 * c, 9 * c, 1, 3 * c, c};
+        const Arr5 e_len{1, nn, k, ho, wo}, e_str{k, ho * wo * k, 1, wo * k, k};
+        const Arr5 bias_str{k, 0, 1, 0, 0};
+        if (s0) {
+            ConvBiasSkip op;
+            auto arg = op.MakeArgument(x0, d_w, std::array<const void *, 2>{d_bias, s0}, y0, a_len, a_str, b_len, b_str,
+                                       std::array<Arr5, 2>{e_len, e_len}, std::array<Arr5, 2>{bias_str, e_str}, e_len, e_str, ones,
+                                       ones, pads, pads, PassThrough{}, PassThrough{}, BiasAddRelu{});
+            if (!op.IsSupportedArgument(arg)) { set_error("sgo_conv3x3_bias_act_dev: shape not supported by the instance"); return SGO_ERR_ARG; }
+            op.MakeInvoker().Run(arg, cfg);
+        } else {
+            ConvBias op;
+            auto arg = op.MakeArgument(x0, d_w, std::array<const void *, 1>{d_bias}, y0, a_len, a_str, b_len, b_str,
+                                       std::array<Arr5, 1>{e_len}, std::array<Arr5, 1>{bias_str}, e_len, e_str, ones, ones, pads,
+                                       pads, PassThrough{}, PassThrough{}, BiasRelu{});
+            if (!op.IsSupportedArgument(arg)) { set_error("sgo_conv3x3_bias_act_dev: shape not supported by the instance"); return SGO_ERR_ARG; }
+            op.MakeInvoker().Run(arg, cfg);
+        }
     }
     SGO_HIP(hipGetLastError());
     return SGO_OK;

@@ -18,7 +18,7 @@ for f in glob.glob("/tmp/pmc_net/*/*kernel_trace.csv"):
     for r in csv.DictReader(open(f)):
         dur.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 out = {"command": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_MFMA GRBM_GUI_ACTIVE --kernel-trace --kernel-include-regex kernel_grouped_conv_fwd -- python3 bench.py --steps 1 --warmup 0 --cpu-baseline 0 --saturated 0",
-       "kernel": "ck::...kernel_grouped_conv_fwd_multiple_abd_xdl_cshuffle (MIOpen ConvHipImplicitGemmGroupFwdXdlops)"}
+       "kernel": "ck::...kernel_grouped_conv_fwd_multiple_abd_xdl_cshuffle with the BiasRelu / BiasAddRelu epilogue of sgo_conv.hip (launches with the bigger batch dominate the upper half)"}
 for k, v in per.items():
     big = sorted(v)[len(v) // 2:]          # the 8192-batch launches dominate; report their mean
     out[k] = {"launches": len(v), "mean_upper_half": sum(big) / len(big)}
