@@ -33,11 +33,11 @@ using DsT = ck::Tuple<F16, F16>;
 
 using V0 = DeviceGroupedConvFwdMultipleABD_Xdl_CShuffle<COMMON, 1, 256, 256, 128, 32, 8, 8, 32, 32, 4, 2, S<4, 64, 1>, S<1, 0, 2>, S<1, 0, 2>, 2, 8, 8, 1, S<4, 64, 1>, S<1, 0, 2>, S<1, 0, 2>, 2, 8, 8, 1, 1, 1, S<1, 32, 1, 8>, 8>;
 #ifdef WANT_V3
-using V1 = DeviceGroupedConvFwdMultipleABD_Xdl_CShuffle_V3<COMMON, 256, 256, 256, 32, 8, 8, 32, 32, 4, 4, S<4, 64, 1>, S<1, 0, 2>, S<1, 0, 2>, 2, 8, 8, 0, S<4, 64, 1>, S<1, 0, 2>, S<1, 0, 2>, 2, 8, 8, 0, 1, 1, S<1, 32, 1, 8>, 8, BlockGemmPipelineScheduler::Intrawave, BlockGemmPipelineVersion::v4>;
-using V2 = DeviceGroupedConvFwdMultipleABD_Xdl_CShuffle_V3<COMMON, 256, 256, 256, 32, 8, 8, 32, 32, 4, 4, S<4, 64, 1>, S<1, 0, 2>, S<1, 0, 2>, 2, 8, 8, 0, S<4, 64, 1>, S<1, 0, 2>, S<1, 0, 2>, 2, 8, 8, 0, 1, 1, S<1, 32, 1, 8>, 8, BlockGemmPipelineScheduler::Intrawave, BlockGemmPipelineVersion::v3>;
-using V3 = DeviceGroupedConvFwdMultipleABD_Xdl_CShuffle_V3<COMMON, 256, 256, 128, 32, 8, 8, 32, 32, 4, 2, S<4, 64, 1>, S<1, 0, 2>, S<1, 0, 2>, 2, 8, 8, 0, S<4, 64, 1>, S<1, 0, 2>, S<1, 0, 2>, 2, 8, 8, 0, 1, 1, S<1, 32, 1, 8>, 8, BlockGemmPipelineScheduler::Intrawave, BlockGemmPipelineVersion::v3>;
-using V4 = DeviceGroupedConvFwdMultipleABD_Xdl_CShuffle_V3<COMMON, 256, 128, 128, 64, 8, 8, 32, 32, 2, 2, S<8, 32, 1>, S<1, 0, 2>, S<1, 0, 2>, 2, 8, 8, 0, S<8, 32, 1>, S<1, 0, 2>, S<1, 0, 2>, 2, 8, 8, 0, 1, 1, S<1, 32, 1, 8>, 8, BlockGemmPipelineScheduler::Intrawave, BlockGemmPipelineVersion::v3>;
-using V5 = DeviceGroupedConvFwdMultipleABD_Xdl_CShuffle_V3<COMMON, 256, 256, 256, 32, 8, 8, 32, 32, 4, 4, S<4, 64, 1>, S<1, 0, 2>, S<1, 0, 2>, 2, 8, 8, 0, S<4, 64, 1>, S<1, 0, 2>, S<1, 0, 2>, 2, 8, 8, 0, 1, 1, S<1, 32, 1, 8>, 8, BlockGemmPipelineScheduler::Intrawave, BlockGemmPipelineVersion::v5>;
+using V1 = DeviceGroupedConvFwdMultipleABD_Xdl_CShuffle<COMMON, 1, 256, 256, 128, 128, 8, 8, 32, 32, 4, 2, S<16, 16, 1>, S<1, 0, 2>, S<1, 0, 2>, 2, 8, 8, 1, S<16, 16, 1>, S<1, 0, 2>, S<1, 0, 2>, 2, 8, 8, 1, 1, 1, S<1, 32, 1, 8>, 8>;
+using V2 = DeviceGroupedConvFwdMultipleABD_Xdl_CShuffle<COMMON, 1, 256, 128, 256, 64, 8, 8, 32, 32, 2, 4, S<8, 32, 1>, S<1, 0, 2>, S<1, 0, 2>, 2, 8, 8, 1, S<8, 32, 1>, S<1, 0, 2>, S<1, 0, 2>, 2, 8, 8, 1, 1, 1, S<1, 32, 1, 8>, 8>;
+using V3 = DeviceGroupedConvFwdMultipleABD_Xdl_CShuffle<COMMON, 1, 256, 128, 128, 64, 8, 8, 32, 32, 2, 2, S<8, 32, 1>, S<1, 0, 2>, S<1, 0, 2>, 2, 8, 8, 1, S<8, 32, 1>, S<1, 0, 2>, S<1, 0, 2>, 2, 8, 8, 1, 1, 1, S<1, 32, 1, 8>, 8>;
+using V4 = DeviceGroupedConvFwdMultipleABD_Xdl_CShuffle<COMMON, 1, 256, 256, 128, 64, 8, 8, 32, 32, 4, 2, S<8, 32, 1>, S<1, 0, 2>, S<1, 0, 2>, 2, 8, 8, 1, S<8, 32, 1>, S<1, 0, 2>, S<1, 0, 2>, 2, 8, 8, 1, 2, 1, S<1, 32, 1, 8>, 8>;
+using V5 = DeviceGroupedConvFwdMultipleABD_Xdl_CShuffle<COMMON, 1, 256, 256, 128, 64, 8, 8, 16, 16, 8, 4, S<8, 32, 1>, S<1, 0, 2>, S<1, 0, 2>, 2, 8, 8, 1, S<8, 32, 1>, S<1, 0, 2>, S<1, 0, 2>, 2, 8, 8, 1, 1, 1, S<1, 32, 1, 8>, 8>;
 #endif
 using Arr5 = std::array<ck::index_t, 5>;
 
@@ -74,11 +74,11 @@ static float run_one(const char *name, int n, int h, int c, int k, const void *x
 extern "C" int ck_sweep(int n, int h, int c, int k, const void *x, const void *w, const void *b, const void *skip, void *y, int iters) {
     run_one<V0>("V0 old   256x256x128x32 4x2", n, h, c, k, x, w, b, skip, y, iters);
 #ifdef WANT_V3
-    run_one<V1>("V1 v3api 256x256x256x32 4x4 pipe v4", n, h, c, k, x, w, b, skip, y, iters);
-    run_one<V2>("V2 v3api 256x256x256x32 4x4 pipe v3", n, h, c, k, x, w, b, skip, y, iters);
-    run_one<V3>("V3 v3api 256x256x128x32 4x2 pipe v3", n, h, c, k, x, w, b, skip, y, iters);
-    run_one<V4>("V4 v3api 256x128x128x64 2x2 pipe v3", n, h, c, k, x, w, b, skip, y, iters);
-    run_one<V5>("V5 v3api 256x256x256x32 4x4 pipe v5", n, h, c, k, x, w, b, skip, y, iters);
+    run_one<V1>("V1 256x256x128 K128", n, h, c, k, x, w, b, skip, y, iters);
+    run_one<V2>("V2 256x128x256 K64", n, h, c, k, x, w, b, skip, y, iters);
+    run_one<V3>("V3 256x128x128 K64", n, h, c, k, x, w, b, skip, y, iters);
+    run_one<V4>("V4 256x256x128 K64 cshuffle 2x1", n, h, c, k, x, w, b, skip, y, iters);
+    run_one<V5>("V5 256x256x128 K64 mfma16x16", n, h, c, k, x, w, b, skip, y, iters);
 #endif
     return 0;
 }
