@@ -31,13 +31,31 @@ using DsL = ck::Tuple<lay::G_K, lay::NHWGK>;
 using DsT = ck::Tuple<F16, F16>;
 #define COMMON 2, lay::NHWGC, lay::GKYXC, DsL, lay::NHWGK, F16, F16, F32, F16, DsT, F16, PassThrough, PassThrough, BiasAddRelu, ConvolutionForwardSpecialization::Default, GemmSpecialization::MNKPadding
 
-using V0 = DeviceGroupedConvFwdMultipleABD_Xdl_CShuffle<COMMON, 1, 256, 256, 128, 32, 8, 8, 32, 32, 4, 2, S<4, 64, 1>, S<1, 0, 2>, S<1, 0, 2>, 2, 8, 8, 1, S<4, 64, 1>, S<1, 0, 2>, S<1, 0, 2>, 2, 8, 8, 1, 1, 1, S<1, 32, 1, 8>, 8>;
-#ifdef WANT_V3
-using V1 = DeviceGroupedConvFwdMultipleABD_Xdl_CShuffle<COMMON, 1, 256, 256, 128, 128, 8, 8, 32, 32, 4, 2, S<16, 16, 1>, S<1, 0, 2>, S<1, 0, 2>, 2, 8, 8, 1, S<16, 16, 1>, S<1, 0, 2>, S<1, 0, 2>, 2, 8, 8, 1, 1, 1, S<1, 32, 1, 8>, 8>;
-using V2 = DeviceGroupedConvFwdMultipleABD_Xdl_CShuffle<COMMON, 1, 256, 128, 256, 64, 8, 8, 32, 32, 2, 4, S<8, 32, 1>, S<1, 0, 2>, S<1, 0, 2>, 2, 8, 8, 1, S<8, 32, 1>, S<1, 0, 2>, S<1, 0, 2>, 2, 8, 8, 1, 1, 1, S<1, 32, 1, 8>, 8>;
-using V3 = DeviceGroupedConvFwdMultipleABD_Xdl_CShuffle<COMMON, 1, 256, 128, 128, 64, 8, 8, 32, 32, 2, 2, S<8, 32, 1>, S<1, 0, 2>, S<1, 0, 2>, 2, 8, 8, 1, S<8, 32, 1>, S<1, 0, 2>, S<1, 0, 2>, 2, 8, 8, 1, 1, 1, S<1, 32, 1, 8>, 8>;
-using V4 = DeviceGroupedConvFwdMultipleABD_Xdl_CShuffle<COMMON, 1, 256, 256, 128, 64, 8, 8, 32, 32, 4, 2, S<8, 32, 1>, S<1, 0, 2>, S<1, 0, 2>, 2, 8, 8, 1, S<8, 32, 1>, S<1, 0, 2>, S<1, 0, 2>, 2, 8, 8, 1, 2, 1, S<1, 32, 1, 8>, 8>;
-using V5 = DeviceGroupedConvFwdMultipleABD_Xdl_CShuffle<COMMON, 1, 256, 256, 128, 64, 8, 8, 16, 16, 8, 4, S<8, 32, 1>, S<1, 0, 2>, S<1, 0, 2>, 2, 8, 8, 1, S<8, 32, 1>, S<1, 0, 2>, S<1, 0, 2>, 2, 8, 8, 1, 1, 1, S<1, 32, 1, 8>, 8>;
+#define TAIL S<1, 0, 2>, S<1, 0, 2>, 2, 8, 8, 1
+#if VARIANT == 0
+using VX = DeviceGroupedConvFwdMultipleABD_Xdl_CShuffle<COMMON, 1, 256, 256, 128, 64, 8, 8, 32, 32, 4, 2, S<8, 32, 1>, TAIL, S<8, 32, 1>, TAIL, 1, 1, S<1, 32, 1, 8>, 8>;
+#define VNAME "256thr 256x128 K64 (product)"
+#elif VARIANT == 1
+using VX = DeviceGroupedConvFwdMultipleABD_Xdl_CShuffle<COMMON, 1, 256, 128, 256, 64, 8, 8, 32, 32, 2, 4, S<8, 32, 1>, TAIL, S<8, 32, 1>, TAIL, 1, 1, S<1, 32, 1, 8>, 8>;
+#define VNAME "256thr 128x256 K64"
+#elif VARIANT == 2
+using VX = DeviceGroupedConvFwdMultipleABD_Xdl_CShuffle<COMMON, 1, 256, 128, 128, 64, 8, 8, 32, 32, 2, 2, S<8, 32, 1>, TAIL, S<8, 32, 1>, TAIL, 1, 1, S<1, 32, 1, 8>, 8>;
+#define VNAME "256thr 128x128 K64"
+#elif VARIANT == 3
+using VX = DeviceGroupedConvFwdMultipleABD_Xdl_CShuffle<COMMON, 1, 256, 256, 128, 128, 8, 8, 32, 32, 4, 2, S<16, 16, 1>, TAIL, S<16, 16, 1>, TAIL, 1, 1, S<1, 32, 1, 8>, 8>;
+#define VNAME "256thr 256x128 K128"
+#elif VARIANT == 4
+using VX = DeviceGroupedConvFwdMultipleABD_Xdl_CShuffle<COMMON, 1, 128, 128, 128, 64, 8, 8, 32, 32, 4, 2, S<8, 16, 1>, TAIL, S<8, 16, 1>, TAIL, 1, 1, S<1, 16, 1, 8>, 8>;
+#define VNAME "128thr 128x128 K64"
+#elif VARIANT == 5
+using VX = DeviceGroupedConvFwdMultipleABD_Xdl_CShuffle<COMMON, 1, 256, 256, 128, 96, 8, 8, 32, 32, 4, 2, S<4, 64, 1>, TAIL, S<4, 64, 1>, TAIL, 1, 1, S<1, 32, 1, 8>, 8>;
+#define VNAME "256thr 256x128 K96"
+#elif VARIANT == 6
+using VX = DeviceGroupedConvFwdMultipleABD_Xdl_CShuffle<COMMON, 1, 256, 256, 64, 64, 8, 8, 32, 32, 2, 2, S<8, 32, 1>, TAIL, S<8, 32, 1>, TAIL, 1, 1, S<1, 32, 1, 8>, 8>;
+#define VNAME "256thr 256x64 K64"
+#elif VARIANT == 7
+using VX = DeviceGroupedConvFwdMultipleABD_Xdl_CShuffle<COMMON, 1, 512, 256, 256, 64, 8, 8, 32, 32, 4, 2, S<8, 64, 1>, TAIL, S<8, 64, 1>, TAIL, 1, 1, S<1, 32, 1, 16>, 8>;
+#define VNAME "512thr 256x256 K64"
 #endif
 using Arr5 = std::array<ck::index_t, 5>;
 
@@ -72,13 +90,6 @@ static float run_one(const char *name, int n, int h, int c, int k, const void *x
 }
 
 extern "C" int ck_sweep(int n, int h, int c, int k, const void *x, const void *w, const void *b, const void *skip, void *y, int iters) {
-    run_one<V0>("V0 old   256x256x128x32 4x2", n, h, c, k, x, w, b, skip, y, iters);
-#ifdef WANT_V3
-    run_one<V1>("V1 256x256x128 K128", n, h, c, k, x, w, b, skip, y, iters);
-    run_one<V2>("V2 256x128x256 K64", n, h, c, k, x, w, b, skip, y, iters);
-    run_one<V3>("V3 256x128x128 K64", n, h, c, k, x, w, b, skip, y, iters);
-    run_one<V4>("V4 256x256x128 K64 cshuffle 2x1", n, h, c, k, x, w, b, skip, y, iters);
-    run_one<V5>("V5 256x256x128 K64 mfma16x16", n, h, c, k, x, w, b, skip, y, iters);
-#endif
+    run_one<VX>(VNAME, n, h, c, k, x, w, b, skip, y, iters);
     return 0;
 }

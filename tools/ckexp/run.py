@@ -1,7 +1,8 @@
 import ctypes as C, os, sys
 import torch
 here = os.path.dirname(os.path.abspath(__file__))
-lib = C.CDLL(os.path.join(here, "libck_sweep.so"))
+import glob
+libs = sorted(glob.glob(os.path.join(here, "libck_v*.so")))
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 h, c, k = 17, 256, 256
 x = (torch.randn(n, c, h, h, device="cuda") * 0.5).half().contiguous(memory_format=torch.channels_last)
@@ -10,5 +11,6 @@ b = torch.randn(k, device="cuda").half()
 s = torch.randn(n, k, h, h, device="cuda").half().contiguous(memory_format=torch.channels_last)
 y = torch.empty_like(s)
 torch.cuda.synchronize()
-lib.ck_sweep(n, h, c, k, C.c_void_p(x.data_ptr()), C.c_void_p(w.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(s.data_ptr()),
-             C.c_void_p(y.data_ptr()), 10)
+for p in libs:
+    C.CDLL(p).ck_sweep(n, h, c, k, C.c_void_p(x.data_ptr()), C.c_void_p(w.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(s.data_ptr()),
+                        C.c_void_p(y.data_ptr()), 10)
