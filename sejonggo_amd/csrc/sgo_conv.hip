@@ -1,9 +1,9 @@
 // sgo_conv.hip -- the residual tower's 3x3 convolution with the bias / skip / ReLU epilogue fused into the GEMM's
 // output stage, for the resident policy/value net (model.py:37-46 of the reference: Conv2D -> BatchNorm (folded) ->
 // [Add] -> ReLU).  The implicit-GEMM main loop is AMD's composable_kernel xdlops (MFMA) grouped-convolution template,
-// instantiated here with the M x N tile MIOpen's tuner selects for this problem on gfx950 (256 threads, 256x128,
-// 32x32 MFMA, 4x2 tiles per wave) but a K step of 64 instead of the library instances' 32 (measured with
-// tools/ckexp: 3.21 vs 3.54 ms per 8192x256x17x17 convolution), and with OUR epilogue functors, so that the separate
+// instantiated here with a tile found by sweeping on gfx950 (tools/ckexp: 256 threads, 128 pixels x 256 channels,
+// 32x32 MFMA, 2x4 tiles per wave, K step 64 -- the library's own instances all use a K step of 32: 3.17 ms vs
+// 3.54 ms per 8192x256x17x17 convolution for the best of those), and with OUR epilogue functors, so that the separate
 // bias/skip/ReLU pass over the 1.2 GB activation tensor disappears.  NHWC fp16 in, fp16 out, fp32 accumulate.
 #include <array>
 
@@ -46,7 +46,7 @@ template <typename DsLayout, typename DsTypes, typename Op>
 using Conv = ck::tensor_operation::device::DeviceGroupedConvFwdMultipleABD_Xdl_CShuffle<
     2, lay::NHWGC, lay::GKYXC, DsLayout, lay::NHWGK, F16, F16, F32, F16, DsTypes, F16, PassThrough, PassThrough, Op,
     ck::tensor_operation::device::ConvolutionForwardSpecialization::Default,
-    ck::tensor_operation::device::GemmSpecialization::MNKPadding, 1, 256, 256, 128, 64, 8, 8, 32, 32, 4, 2, S<8, 32, 1>,
+    ck::tensor_operation::device::GemmSpecialization::MNKPadding, 1, 256, 128, 256, 64, 8, 8, 32, 32, 2, 4, S<8, 32, 1>,
     S<1, 0, 2>, S<1, 0, 2>, 2, 8, 8, 1, S<8, 32, 1>, S<1, 0, 2>, S<1, 0, 2>, 2, 8, 8, 1, 1, 1, S<1, 32, 1, 8>, 8>;
 
 using ConvBias = Conv<ck::Tuple<lay::G_K>, ck::Tuple<F16>, BiasRelu>;

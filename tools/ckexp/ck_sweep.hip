@@ -1,4 +1,4 @@
-// Experiment: time several composable_kernel grouped-conv instances (old pipeline + V3 pipelines) with the fused
+// Experiment: time composable_kernel grouped-conv tile variants (one per -DVARIANT=n build) with the fused
 // bias+skip+ReLU epilogue on the tower shape.  Built and run by tools/ckexp/run.py; not part of the product library.
 #include <array>
 #include <cstdio>
@@ -34,10 +34,10 @@ using DsT = ck::Tuple<F16, F16>;
 #define TAIL S<1, 0, 2>, S<1, 0, 2>, 2, 8, 8, 1
 #if VARIANT == 0
 using VX = DeviceGroupedConvFwdMultipleABD_Xdl_CShuffle<COMMON, 1, 256, 256, 128, 64, 8, 8, 32, 32, 4, 2, S<8, 32, 1>, TAIL, S<8, 32, 1>, TAIL, 1, 1, S<1, 32, 1, 8>, 8>;
-#define VNAME "256thr 256x128 K64 (product)"
+#define VNAME "256thr 256x128 K64"
 #elif VARIANT == 1
 using VX = DeviceGroupedConvFwdMultipleABD_Xdl_CShuffle<COMMON, 1, 256, 128, 256, 64, 8, 8, 32, 32, 2, 4, S<8, 32, 1>, TAIL, S<8, 32, 1>, TAIL, 1, 1, S<1, 32, 1, 8>, 8>;
-#define VNAME "256thr 128x256 K64"
+#define VNAME "256thr 128x256 K64 (product)"
 #elif VARIANT == 2
 using VX = DeviceGroupedConvFwdMultipleABD_Xdl_CShuffle<COMMON, 1, 256, 128, 128, 64, 8, 8, 32, 32, 2, 2, S<8, 32, 1>, TAIL, S<8, 32, 1>, TAIL, 1, 1, S<1, 32, 1, 8>, 8>;
 #define VNAME "256thr 128x128 K64"
@@ -53,9 +53,6 @@ using VX = DeviceGroupedConvFwdMultipleABD_Xdl_CShuffle<COMMON, 1, 256, 256, 128
 #elif VARIANT == 6
 using VX = DeviceGroupedConvFwdMultipleABD_Xdl_CShuffle<COMMON, 1, 256, 256, 64, 64, 8, 8, 32, 32, 2, 2, S<8, 32, 1>, TAIL, S<8, 32, 1>, TAIL, 1, 1, S<1, 32, 1, 8>, 8>;
 #define VNAME "256thr 256x64 K64"
-#elif VARIANT == 7
-using VX = DeviceGroupedConvFwdMultipleABD_Xdl_CShuffle<COMMON, 1, 512, 256, 256, 64, 8, 8, 32, 32, 4, 2, S<8, 64, 1>, TAIL, S<8, 64, 1>, TAIL, 1, 1, S<1, 32, 1, 16>, 8>;
-#define VNAME "512thr 256x256 K64"
 #endif
 using Arr5 = std::array<ck::index_t, 5>;
 
