@@ -12,8 +12,10 @@
  *   board17   int32 [n][S][S][17]  the reference's board tensor (play.py:295-299), NHWC, plane 2k =
  *             to-play side's stones k plies ago, 2k+1 = opponent's, plane 16 = to-play colour (+1/-1).
  *   action    a = y*S + x, pass = S*S                                   (play.py:31-37)
- *   packed    uint32 [n][sgo_packed_words(S)]  16 bit-planes of ceil(S*S/32) words (bit a of plane c
- *             = board17[...a..., c] != 0) + 1 meta word (bit0: to-play is white), padded to 16 B.
+ *   packed    uint32 [n][sgo_packed_words(S)]  16 bit-planes of ceil(S*S/32) words, ABSOLUTE colours: bit a of plane
+ *             2k = black stone at a, k plies ago; plane 2k+1 = white (board17's planes are relative to the side to
+ *             move: relative plane c = absolute plane c ^ [white to play]).  The to-play flag is the top bit of the
+ *             last word of plane 0 (1 = white to play).  19x19: 192 words = 768 B.
  *   legal     uint32 [n][sgo_plane_words(S)]   bit a = 1 <=> action a is LEGAL (pass bit always 1).
  *   *_dev     arguments are DEVICE pointers; `stream` is a hipStream_t passed as void*.
  *   host entry points (no _dev suffix) copy caller HOST buffers to the GPU, run the same kernels and

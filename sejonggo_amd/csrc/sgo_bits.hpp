@@ -25,8 +25,13 @@ struct Geo {
     static constexpr int NW = (N + 31) / 32;   // words per bit-plane
     static constexpr int MW = (A + 31) / 32;   // words per legal bitset (incl. pass bit)
     static constexpr int APAD = NW * 32;       // child slots per tree block
-    static constexpr int RW = ((16 * NW + 1 + 3) / 4) * 4;  // words per packed position record
-    static constexpr int META = 16 * NW;       // index of the meta word
+    static constexpr int RW = 16 * NW;         // words per packed position record (19x19: 768 B = six 128-B lines)
+    // Record layout: plane 2k = BLACK stones k plies ago, plane 2k+1 = WHITE stones k plies ago (absolute colours,
+    // so that one ply is "pairs 0..6 move to pairs 1..7" -- a contiguous copy -- and a colour override needs no plane
+    // swap).  The to-play bit lives in the spare top bit of plane 0's last word (S*S < 32*NW for every supported size).
+    static constexpr int META_WORD = NW - 1;
+    static constexpr uint32_t META_BIT = 0x80000000u;
+    static_assert(S * S < 32 * NW, "need a spare bit in the last plane word");
     static constexpr uint32_t ROWMASK = (1u << S) - 1u;
     static_assert(MW == NW, "pass bit must fit in the last plane word");
     static_assert(S >= 2 && S <= 19, "board size");
@@ -362,85 +367,80 @@ SGO_DEV void store_plane(uint32_t *rec, int plane, const uint32_t (&w)[Geo<S>::N
     }
 }
 
-// Full ply on a packed record, fused with the legal set of the resulting position.
-//   in / out may be the same record.  swap_first: make_play's `color != to-play` branch (play.py:227-228).
-// Returns 0 or a negative status (record untouched).
 template <int S>
-SGO_DEV int advance_record(const uint32_t *in, uint32_t *out, int a, bool swap_first, uint32_t *legal_out) {
+SGO_DEV bool white_to_play(const uint32_t *rec) { return (rec[Geo<S>::META_WORD] & Geo<S>::META_BIT) != 0; }
+
+// Core of one ply on the current pair (planes 0,1 = black, white): returns the new pair packed (meta bit set for the
+// new side to move) and, optionally, the legal set of the new position.
+template <int S>
+SGO_DEV int advance_pair(const uint32_t *in, int a, bool swap_first, uint32_t (&n0)[Geo<S>::NW], uint32_t (&n1)[Geo<S>::NW],
+                         uint32_t *legal_out) {
     using G = Geo<S>;
     if (a < 0 || a > G::N) return -102;
     uint32_t w0[G::NW], w1[G::NW];
-    load_plane<S>(in, swap_first ? 1 : 0, w0);
-    load_plane<S>(in, swap_first ? 0 : 1, w1);
-    uint32_t meta = in[G::META];
-    uint32_t own[S], opp[S], before_opp[S];
-    unpack_rows<S>(w0, own);
-    unpack_rows<S>(w1, opp);
+    load_plane<S>(in, 0, w0);
+    load_plane<S>(in, 1, w1);
+    // make_play's `color != to-play` branch (play.py:227-228) only changes who moves: colours are absolute here
+    const bool mover_white = ((w0[G::META_WORD] & G::META_BIT) != 0) != swap_first;
+    uint32_t bl[S], wh[S], own[S], opp[S], before_opp[S];
+    unpack_rows<S>(w0, bl);
+    unpack_rows<S>(w1, wh);
 #pragma unroll
-    for (int y = 0; y < S; y++) before_opp[y] = opp[y];
+    for (int y = 0; y < S; y++) {
+        own[y] = mover_white ? wh[y] : bl[y];
+        opp[y] = mover_white ? bl[y] : wh[y];
+        before_opp[y] = opp[y];
+    }
     int st = advance_core<S>(own, opp, a);
     if (st) return st;
-    // history: after the shift + pair swap, new plane 2k = old plane 2k-1, new 2k+1 = old 2k-2 (old = the
-    // position as the mover saw it, i.e. after swap_first).  Highest planes first => safe in place.
-#pragma unroll 1
-    for (int k = 7; k >= 1; k--) {
-        uint32_t ha[G::NW], hb[G::NW];
-        load_plane<S>(in, swap_first ? 2 * k - 2 : 2 * k - 1, ha);
-        load_plane<S>(in, swap_first ? 2 * k - 1 : 2 * k - 2, hb);
-        store_plane<S>(out, 2 * k, ha);
-        store_plane<S>(out, 2 * k + 1, hb);
+#pragma unroll
+    for (int y = 0; y < S; y++) {
+        bl[y] = mover_white ? opp[y] : own[y];
+        wh[y] = mover_white ? own[y] : opp[y];
     }
-    uint32_t n0[G::NW], n1[G::NW];
-    pack_rows<S>(opp, n0);  // new to-play side = old opponent
-    pack_rows<S>(own, n1);
-    store_plane<S>(out, 0, n0);
-    store_plane<S>(out, 1, n1);
-    // to-play flips once per make_play; swap_first flips it once more beforehand
-    uint32_t white_to_play = (meta & 1u) ^ (swap_first ? 1u : 0u) ^ 1u;
-    out[G::META] = (meta & ~1u) | white_to_play;
+    pack_rows<S>(bl, n0);
+    pack_rows<S>(wh, n1);
+    if (!mover_white) n0[G::META_WORD] |= G::META_BIT;   // black moved => white to play
     if (legal_out) {
         uint32_t legal[S], lw[G::NW];
-        legal_core<S>(opp, own, before_opp, legal);
+        legal_core<S>(opp, own, before_opp, legal);       // new side to move = old opponent
         pack_rows<S>(legal, lw);
-        lw[G::N >> 5] |= 1u << (G::N & 31);  // pass is always legal
+        lw[G::N >> 5] |= 1u << (G::N & 31);               // pass is always legal
 #pragma unroll
         for (int i = 0; i < G::NW; i++) legal_out[i] = lw[i];
     }
     return 0;
 }
 
-// The same ply WITHOUT the history planes: reads planes 0,1 + meta of `in`, writes planes 0,1 + meta of
-// `out` and the legal set.  Planes 2..15 are moved by the separate streaming kernel k_history_shift (only
-// valid when in and out do not alias).
+// Full ply on a packed record, fused with the legal set of the resulting position.  in / out may be the same
+// record: the history pairs move from the highest plane down.  Returns 0 or a negative status (record untouched).
+template <int S>
+SGO_DEV int advance_record(const uint32_t *in, uint32_t *out, int a, bool swap_first, uint32_t *legal_out) {
+    using G = Geo<S>;
+    uint32_t n0[G::NW], n1[G::NW];
+    int st = advance_pair<S>(in, a, swap_first, n0, n1, legal_out);
+    if (st) return st;
+#pragma unroll 1
+    for (int p = 15; p >= 2; p--) {
+        uint32_t h[G::NW];
+        load_plane<S>(in, p - 2, h);
+        store_plane<S>(out, p, h);
+    }
+    store_plane<S>(out, 0, n0);
+    store_plane<S>(out, 1, n1);
+    return 0;
+}
+
+// The same ply WITHOUT the history planes: writes planes 0,1 of `out` and the legal set.  Planes 2..15 are moved by
+// the streaming kernel k_history_shift (only valid when in and out do not alias).
 template <int S>
 SGO_DEV int advance_planes(const uint32_t *in, uint32_t *out, int a, bool swap_first, uint32_t *legal_out) {
     using G = Geo<S>;
-    if (a < 0 || a > G::N) return -102;
-    uint32_t w0[G::NW], w1[G::NW];
-    load_plane<S>(in, swap_first ? 1 : 0, w0);
-    load_plane<S>(in, swap_first ? 0 : 1, w1);
-    const uint32_t meta = in[G::META];
-    uint32_t own[S], opp[S], before_opp[S];
-    unpack_rows<S>(w0, own);
-    unpack_rows<S>(w1, opp);
-#pragma unroll
-    for (int y = 0; y < S; y++) before_opp[y] = opp[y];
-    int st = advance_core<S>(own, opp, a);
-    if (st) return st;
     uint32_t n0[G::NW], n1[G::NW];
-    pack_rows<S>(opp, n0);
-    pack_rows<S>(own, n1);
+    int st = advance_pair<S>(in, a, swap_first, n0, n1, legal_out);
+    if (st) return st;
     store_plane<S>(out, 0, n0);
     store_plane<S>(out, 1, n1);
-    out[G::META] = (meta & ~1u) | ((meta & 1u) ^ (swap_first ? 1u : 0u) ^ 1u);
-    if (legal_out) {
-        uint32_t legal[S], lw[G::NW];
-        legal_core<S>(opp, own, before_opp, legal);
-        pack_rows<S>(legal, lw);
-        lw[G::N >> 5] |= 1u << (G::N & 31);
-#pragma unroll
-        for (int i = 0; i < G::NW; i++) legal_out[i] = lw[i];
-    }
     return 0;
 }
 
@@ -448,11 +448,12 @@ template <int S>
 SGO_DEV void legal_record(const uint32_t *rec, uint32_t *legal_out) {
     using G = Geo<S>;
     uint32_t w[G::NW], own[S], opp[S], prev[S], legal[S], lw[G::NW];
-    load_plane<S>(rec, 0, w);
+    const bool wtp = white_to_play<S>(rec);
+    load_plane<S>(rec, wtp ? 1 : 0, w);
     unpack_rows<S>(w, own);
-    load_plane<S>(rec, 1, w);
+    load_plane<S>(rec, wtp ? 0 : 1, w);
     unpack_rows<S>(w, opp);
-    load_plane<S>(rec, 2, w);
+    load_plane<S>(rec, wtp ? 3 : 2, w);     // the side to move, one ply ago
     unpack_rows<S>(w, prev);
     legal_core<S>(own, opp, prev, legal);
     pack_rows<S>(legal, lw);
@@ -464,13 +465,12 @@ SGO_DEV void legal_record(const uint32_t *rec, uint32_t *legal_out) {
 template <int S>
 SGO_DEV void score_record(const uint32_t *rec, int &bp, int &wp) {
     using G = Geo<S>;
-    uint32_t w[G::NW], own[S], opp[S];
+    uint32_t w[G::NW], bl[S], wh[S];
     load_plane<S>(rec, 0, w);
-    unpack_rows<S>(w, own);
+    unpack_rows<S>(w, bl);
     load_plane<S>(rec, 1, w);
-    unpack_rows<S>(w, opp);
-    if (rec[G::META] & 1u) score_core<S>(opp, own, bp, wp);  // white to play: plane 0 is white
-    else score_core<S>(own, opp, bp, wp);
+    unpack_rows<S>(w, wh);
+    score_core<S>(bl, wh, bp, wp);
 }
 
 }  // namespace sgo

@@ -243,7 +243,7 @@ struct Eng {
         const size_t fo = (size_t)g * (2 * MAXE) + fi;
         const int pb = c.fParent[fo], slot = c.fSlot[fo], nb = c.fBlk[fo];
         const float vraw = c.fValue[fo];
-        const int leaf_player = (c.pos[(gb0 + nb) * G::RW + G::META] & 1u) ? -1 : 1;
+        const int leaf_player = white_to_play<S>(c.pos + (gb0 + nb) * G::RW) ? -1 : 1;
         const float v = (leaf_player == st.original_player) ? vraw : -vraw;
         float leaf_value = 0.f;
         if (lane == (slot & 63)) {
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(64) void k_search(Ctx c, const float *policy, const
                 if (run) {
                     st.rounds_left = c.cfg.sims / c.cfg.energy;
                     st.e_left = -1;
-                    st.original_player = (c.pos[(e.gb0 + st.root_blk) * G::RW + G::META] & 1u) ? -1 : 1;
+                    st.original_player = white_to_play<S>(c.pos + (e.gb0 + st.root_blk) * G::RW) ? -1 : 1;
                     st.phase = PH_SEARCH;
                     if (c.cfg.sims < c.cfg.energy) fail(SGO_ERR_STATE);  // zero simulations: the reference cannot pick a move
                 }
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(64) void k_search(Ctx c, const float *policy, const
             st.root_count = __shfl(rc, selected & 63);
             st.root_value = __shfl(rv, selected & 63);
             st.root_mean = __shfl(rm, selected & 63);
-            const int mover = (c.pos[(e.gb0 + st.root_blk) * G::RW + G::META] & 1u) ? -1 : 1;
+            const int mover = white_to_play<S>(c.pos + (e.gb0 + st.root_blk) * G::RW) ? -1 : 1;
             st.root_blk = nr;
             st.root_f64 = 0;
             if (lane == 0) { c.bParent[e.gb0 + nr] = -1; c.bSlot[e.gb0 + nr] = -1; }

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void k_advance_legal(int n, const uint32_t *in
     uint32_t *dst = out + (size_t)(out_idx ? out_idx[i] : i) * G::RW;
     uint32_t *lg = legal ? legal + (size_t)(legal_idx ? legal_idx[i] : i) * G::NW : nullptr;
     bool swap_first = false;
-    int mover = (src[G::META] & 1u) ? -1 : 1;
+    int mover = white_to_play<S>(src) ? -1 : 1;
     if (colors) {
         int c = colors[i];
         if (c != 0 && c != mover) { swap_first = true; mover = -mover; }
@@ -108,25 +108,15 @@ template <int S>
 __device__ __forceinline__ void history_shift_body(int n, long t0, long stride, const uint32_t *in, const int32_t *in_idx,
                                                    const int32_t *colors, uint32_t *out, const int32_t *out_idx) {
     using G = Geo<S>;
+    (void)colors;                                   // colours are absolute in the record: an override moves no plane
     constexpr bool V4 = (G::NW % 4 == 0);
-    constexpr int CPP = V4 ? G::NW / 4 : G::NW;   // chunks per plane
-    constexpr int CPR = 14 * CPP;                 // chunks per record
+    constexpr int WPC = V4 ? 4 : 1;                 // words per chunk
+    constexpr int CPR = 14 * G::NW / WPC;           // chunks per record: planes 0..13 -> planes 2..15, one contiguous run
     const long total = (long)n * CPR;
     auto addr = [&](long t, const uint32_t *&sp_, uint32_t *&dp_) {
         const int i = (int)(t / CPR), c = (int)(t - (long)i * CPR);
-        const int p = 2 + c / CPP, w = c - (p - 2) * CPP;
-        const uint32_t *src = in + (size_t)(in_idx ? in_idx[i] : i) * G::RW;
-        uint32_t *dst = out + (size_t)(out_idx ? out_idx[i] : i) * G::RW;
-        bool swap_first = false;
-        if (colors) {
-            const int mover = (src[G::META] & 1u) ? -1 : 1;
-            const int col = colors[i];
-            swap_first = (col != 0 && col != mover);
-        }
-        const int sp = swap_first ? p - 2 : ((p & 1) ? p - 3 : p - 1);
-        constexpr int WPC = V4 ? 4 : 1;
-        sp_ = src + sp * G::NW + w * WPC;
-        dp_ = dst + p * G::NW + w * WPC;
+        sp_ = in + (size_t)(in_idx ? in_idx[i] : i) * G::RW + c * WPC;
+        dp_ = out + (size_t)(out_idx ? out_idx[i] : i) * G::RW + 2 * G::NW + c * WPC;
     };
     for (long t = t0; t < total; t += 4 * stride) {
         // four independent chunks in flight per thread
@@ -179,7 +169,7 @@ __global__ __launch_bounds__(64) void k_advance_planes(int n, const int *n_dev, 
     uint32_t *dst = out + (size_t)(out_idx ? out_idx[i] : i) * G::RW;
     uint32_t *lg = legal ? legal + (size_t)(legal_idx ? legal_idx[i] : i) * G::NW : nullptr;
     bool swap_first = false;
-    int mover = (src[G::META] & 1u) ? -1 : 1;
+    int mover = white_to_play<S>(src) ? -1 : 1;
     if (colors) {
         int c = colors[i];
         if (c != 0 && c != mover) { swap_first = true; mover = -mover; }
@@ -209,7 +199,7 @@ __global__ __launch_bounds__(64) void k_board_advance(int n, const int *n_dev, i
     uint32_t *dst = out + (size_t)(out_idx ? out_idx[i] : i) * G::RW;
     uint32_t *lg = legal ? legal + (size_t)(legal_idx ? legal_idx[i] : i) * G::NW : nullptr;
     bool swap_first = false;
-    int mover = (src[G::META] & 1u) ? -1 : 1;
+    int mover = white_to_play<S>(src) ? -1 : 1;
     if (colors) {
         int c = colors[i];
         if (c != 0 && c != mover) { swap_first = true; mover = -mover; }
@@ -241,7 +231,9 @@ __global__ __launch_bounds__(256) void k_score(int n, const uint32_t *packed, co
     result[3 * i + 2] = wp;
 }
 
-// one block per board, one thread per point (rounded up to whole waves); wave ballots build the words
+// one block per board, one thread per point (rounded up to whole waves); wave ballots build the words.
+// The board tensor's planes are relative to the side to move (2k = to-play, 2k+1 = opponent); the record's are
+// absolute (2k = black, 2k+1 = white): relative plane c maps to absolute plane c ^ (white to play).
 template <int S>
 __global__ void k_pack(int n, const int32_t *boards, uint32_t *packed) {
     using G = Geo<S>;
@@ -250,17 +242,19 @@ __global__ void k_pack(int n, const int32_t *boards, uint32_t *packed) {
     const int32_t *src = boards + (size_t)b * G::N * 17;
     uint32_t *dst = packed + (size_t)b * G::RW;
     int wave = t >> 6, lane = t & 63;
+    const int flip = (src[16] == -1) ? 1 : 0;
     for (int c = 0; c < 16; c++) {
-        int v = (t < G::N) ? (src[t * 17 + c] != 0) : 0;
+        int v = (t < G::N) ? (src[t * 17 + (c ^ flip)] != 0) : 0;   // absolute plane c comes from relative plane c ^ flip
         unsigned long long m = __ballot(v);
         if (lane == 0) {
-            if (2 * wave < G::NW) dst[c * G::NW + 2 * wave] = (uint32_t)m;
-            if (2 * wave + 1 < G::NW) dst[c * G::NW + 2 * wave + 1] = (uint32_t)(m >> 32);
+            uint32_t lo = (uint32_t)m, hi = (uint32_t)(m >> 32);
+            if (c == 0 && flip) {
+                if (2 * wave == G::META_WORD) lo |= G::META_BIT;
+                if (2 * wave + 1 == G::META_WORD) hi |= G::META_BIT;
+            }
+            if (2 * wave < G::NW) dst[c * G::NW + 2 * wave] = lo;
+            if (2 * wave + 1 < G::NW) dst[c * G::NW + 2 * wave + 1] = hi;
         }
-    }
-    if (t == 0) {
-        dst[G::META] = (src[16] == -1) ? 1u : 0u;
-        for (int i = G::META + 1; i < G::RW; i++) dst[i] = 0;
     }
 }
 
@@ -272,8 +266,9 @@ __global__ void k_unpack(int n, const uint32_t *packed, int32_t *boards) {
     if (t >= G::N) return;
     const uint32_t *src = packed + (size_t)b * G::RW;
     int32_t *dst = boards + ((size_t)b * G::N + t) * 17;
-    for (int c = 0; c < 16; c++) dst[c] = (src[c * G::NW + (t >> 5)] >> (t & 31)) & 1u;
-    dst[16] = (src[G::META] & 1u) ? -1 : 1;
+    const int flip = white_to_play<S>(src) ? 1 : 0;
+    for (int c = 0; c < 16; c++) dst[c] = (src[(c ^ flip) * G::NW + (t >> 5)] >> (t & 31)) & 1u;
+    dst[16] = flip ? -1 : 1;
 }
 
 // network input: out[i] = symmetry_k(position idx[i]).  One thread per (entry, point).
@@ -289,9 +284,10 @@ __global__ __launch_bounds__(256) void k_nn_pack(int n, const uint32_t *packed, 
     int sp = si * S + sj;
     const uint32_t *rec = packed + (size_t)(idx ? idx[e] : e) * G::RW;
     T vals[17];
+    const int flip = white_to_play<S>(rec) ? 1 : 0;   // network planes are relative to the side to move
 #pragma unroll
-    for (int c = 0; c < 16; c++) vals[c] = (T)(float)((rec[c * G::NW + (sp >> 5)] >> (sp & 31)) & 1u);
-    vals[16] = (T)((rec[G::META] & 1u) ? -1.0f : 1.0f);
+    for (int c = 0; c < 16; c++) vals[c] = (T)(float)((rec[(c ^ flip) * G::NW + (sp >> 5)] >> (sp & 31)) & 1u);
+    vals[16] = (T)(flip ? -1.0f : 1.0f);
     if (layout == 0) {  // NHWC
         T *o = out + ((size_t)e * G::N + pt) * 17;
 #pragma unroll
@@ -384,7 +380,7 @@ int launch_advance_split(int S, int n_max, const int *d_n, const uint32_t *d_in,
     int mode = adv_mode();
     if (mode < 0) mode = (n_max <= (1 << 16)) ? 1 : 0;
     SGO_DISPATCH(S, {
-        constexpr int CPR = 14 * ((Geo<kS>::NW % 4 == 0) ? Geo<kS>::NW / 4 : Geo<kS>::NW);
+        constexpr int CPR = (Geo<kS>::NW % 4 == 0) ? 14 * Geo<kS>::NW / 4 : 14 * Geo<kS>::NW;
         if (mode == 1) {
             const int nbc = cdiv(n_max, 64);
             long nbs = ((long)n_max * CPR + 255) / 256;
@@ -479,7 +475,7 @@ int sgo_set_device(int d) {
 }
 
 int sgo_plane_words(int S) { return size_ok(S) ? (S * S + 31) / 32 : SGO_ERR_ARG; }
-int sgo_packed_words(int S) { return size_ok(S) ? ((16 * ((S * S + 31) / 32) + 1 + 3) / 4) * 4 : SGO_ERR_ARG; }
+int sgo_packed_words(int S) { return size_ok(S) ? 16 * ((S * S + 31) / 32) : SGO_ERR_ARG; }
 int sgo_apad(int S) { return size_ok(S) ? 32 * ((S * S + 31) / 32) : SGO_ERR_ARG; }
 
 int sgo_sym_lut(int S, int k, int32_t *lut) {

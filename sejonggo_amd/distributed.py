@@ -12,7 +12,7 @@ import numpy as np
 def tuple_dtype(size):
     N = size * size
     NW = (N + 31) // 32
-    RW = ((16 * NW + 1 + 3) // 4) * 4
+    RW = 16 * NW
     return np.dtype([("rank", "<i4"), ("game", "<i4"), ("game_seq", "<i4"), ("move_n", "<i4"), ("action", "<i4"),
                      ("player", "<i4"), ("value", "<f4"), ("z", "<f4"), ("state", "<u4", (RW,)),
                      ("pi", "<f4", (N + 1,))])

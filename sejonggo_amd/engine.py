@@ -24,18 +24,21 @@ END_REASONS = {0: "PLAYED ALL MOVES", 1: "resign", 2: "BOTH_PASSED"}
 
 
 def unpack_positions(packed, size):
-    """packed uint32 [n, RW] -> the reference's board tensor int32 [n, S, S, 17] (host-side format
-    conversion for move records; the hot path never leaves the packed form)."""
+    """packed uint32 [n, RW] -> the reference's board tensor int32 [n, S, S, 17] (host-side format conversion for
+    move records; the hot path never leaves the packed form).  Record planes are absolute (2k black, 2k+1 white,
+    k plies ago) with the to-play bit in the top bit of plane 0's last word; the tensor's planes are relative to the
+    side to move (include/sgo.h)."""
     packed = np.ascontiguousarray(packed, dtype=np.uint32)
     n = packed.shape[0]
     N = size * size
     NW = (N + 31) // 32
     planes = packed[:, :16 * NW].reshape(n, 16, NW)
+    white = ((planes[:, 0, NW - 1] >> np.uint32(31)) & np.uint32(1)).astype(bool)
     bits = np.unpackbits(planes.view(np.uint8).reshape(n, 16, NW * 4), axis=2, bitorder="little")[:, :, :N]
+    rel = np.where(white[:, None, None], bits[:, np.arange(16) ^ 1, :], bits)       # relative plane c = absolute c ^ white
     boards = np.zeros((n, size, size, 17), dtype=np.int32)
-    boards[:, :, :, :16] = bits.transpose(0, 2, 1).reshape(n, size, size, 16)
-    to_play = np.where(packed[:, 16 * NW] & 1, -1, 1).astype(np.int32)
-    boards[:, :, :, 16] = to_play[:, None, None]
+    boards[:, :, :, :16] = rel.transpose(0, 2, 1).reshape(n, size, size, 16)
+    boards[:, :, :, 16] = np.where(white, -1, 1).astype(np.int32)[:, None, None]
     return boards
 
 

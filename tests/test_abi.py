@@ -32,7 +32,7 @@ def test_geometry_and_errors():
     lib = L.load()
     assert lib.sgo_version() >= 1
     assert [lib.sgo_plane_words(s) for s in L.SUPPORTED_SIZES] == [1, 2, 3, 6, 12]
-    assert [lib.sgo_packed_words(s) for s in L.SUPPORTED_SIZES] == [20, 36, 52, 100, 196]
+    assert [lib.sgo_packed_words(s) for s in L.SUPPORTED_SIZES] == [16, 32, 48, 96, 192]
     assert lib.sgo_apad(19) == 384 and lib.sgo_apad(9) == 96
     assert lib.sgo_plane_words(8) < 0  # unsupported size is an error, not a fallback
 

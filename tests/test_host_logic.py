@@ -84,22 +84,26 @@ def test_sample_writer_layout(tmp_path):
 
 
 def test_unpack_positions_inverts_the_packed_layout():
+    """Packed record (include/sgo.h): plane 2k = black / 2k+1 = white k plies ago, to-play bit = top bit of plane 0's
+    last word; the board tensor's planes are relative to the side to move."""
     from sejonggo_amd.engine import unpack_positions
     rng = np.random.RandomState(1)
     for S in (5, 9, 19):
         N = S * S
         NW = (N + 31) // 32
-        RW = ((16 * NW + 1 + 3) // 4) * 4
+        RW = 16 * NW
         boards = np.zeros((6, S, S, 17), np.int32)
         boards[..., :16] = rng.randint(0, 2, size=(6, S, S, 16))
         boards[..., 16] = rng.choice([-1, 1], size=6)[:, None, None]
         packed = np.zeros((6, RW), np.uint32)
         for b in range(6):
+            white = boards[b, 0, 0, 16] == -1
             for c in range(16):
-                bits = boards[b, :, :, c].reshape(-1)
-                for a in np.flatnonzero(bits):
-                    packed[b, c * NW + (a >> 5)] |= np.uint32(1 << (a & 31))
-            packed[b, 16 * NW] = 1 if boards[b, 0, 0, 16] == -1 else 0
+                absolute = c ^ 1 if white else c
+                for a in np.flatnonzero(boards[b, :, :, c].reshape(-1)):
+                    packed[b, absolute * NW + (a >> 5)] |= np.uint32(1 << (a & 31))
+            if white:
+                packed[b, NW - 1] |= np.uint32(1 << 31)
         assert np.array_equal(unpack_positions(packed, S), boards)
 
 
