@@ -370,45 +370,49 @@ SGO_DEV void store_plane(uint32_t *rec, int plane, const uint32_t (&w)[Geo<S>::N
 template <int S>
 SGO_DEV bool white_to_play(const uint32_t *rec) { return (rec[Geo<S>::META_WORD] & Geo<S>::META_BIT) != 0; }
 
-// Core of one ply on the current pair (planes 0,1 = black, white): returns the new pair packed (meta bit set for the
-// new side to move) and, optionally, the legal set of the new position.
+// Core of one ply on the current pair.  p0/p1 are filled with planes 0,1 (black, white) of `in`, and on return hold
+// the new pair (meta bit set for the new side to move); optionally the legal set of the new position is produced.
 template <int S>
-SGO_DEV int advance_pair(const uint32_t *in, int a, bool swap_first, uint32_t (&n0)[Geo<S>::NW], uint32_t (&n1)[Geo<S>::NW],
+SGO_DEV int advance_pair(const uint32_t *in, int a, bool swap_first, uint32_t (&p0)[Geo<S>::NW], uint32_t (&p1)[Geo<S>::NW],
                          uint32_t *legal_out) {
     using G = Geo<S>;
     if (a < 0 || a > G::N) return -102;
-    uint32_t w0[G::NW], w1[G::NW];
-    load_plane<S>(in, 0, w0);
-    load_plane<S>(in, 1, w1);
+    load_plane<S>(in, 0, p0);
+    load_plane<S>(in, 1, p1);
     // make_play's `color != to-play` branch (play.py:227-228) only changes who moves: colours are absolute here
-    const bool mover_white = ((w0[G::META_WORD] & G::META_BIT) != 0) != swap_first;
-    uint32_t bl[S], wh[S], own[S], opp[S], before_opp[S];
-    unpack_rows<S>(w0, bl);
-    unpack_rows<S>(w1, wh);
+    const bool mover_white = ((p0[G::META_WORD] & G::META_BIT) != 0) != swap_first;
+    // mover / opponent are picked at the packed-word level (NW swaps, no extra row arrays stay live)
 #pragma unroll
-    for (int y = 0; y < S; y++) {
-        own[y] = mover_white ? wh[y] : bl[y];
-        opp[y] = mover_white ? bl[y] : wh[y];
-        before_opp[y] = opp[y];
+    for (int i = 0; i < G::NW; i++) {
+        const uint32_t b = p0[i], w = p1[i];
+        p0[i] = mover_white ? w : b;
+        p1[i] = mover_white ? b : w;
     }
+    uint32_t own[S], opp[S];
+    unpack_rows<S>(p0, own);
+    unpack_rows<S>(p1, opp);
     int st = advance_core<S>(own, opp, a);
     if (st) return st;
-#pragma unroll
-    for (int y = 0; y < S; y++) {
-        bl[y] = mover_white ? opp[y] : own[y];
-        wh[y] = mover_white ? own[y] : opp[y];
-    }
-    pack_rows<S>(bl, n0);
-    pack_rows<S>(wh, n1);
-    if (!mover_white) n0[G::META_WORD] |= G::META_BIT;   // black moved => white to play
     if (legal_out) {
-        uint32_t legal[S], lw[G::NW];
-        legal_core<S>(opp, own, before_opp, legal);       // new side to move = old opponent
+        // new side to move = old opponent; its stones one ply ago = the opponent plane as loaded (still in p1)
+        uint32_t before_opp[S], legal[S];
+        unpack_rows<S>(p1, before_opp);
+        legal_core<S>(opp, own, before_opp, legal);
+        uint32_t lw[G::NW];
         pack_rows<S>(legal, lw);
         lw[G::N >> 5] |= 1u << (G::N & 31);               // pass is always legal
 #pragma unroll
         for (int i = 0; i < G::NW; i++) legal_out[i] = lw[i];
     }
+    pack_rows<S>(own, p0);
+    pack_rows<S>(opp, p1);
+#pragma unroll
+    for (int i = 0; i < G::NW; i++) {
+        const uint32_t o = p0[i], p = p1[i];
+        p0[i] = mover_white ? p : o;   // black
+        p1[i] = mover_white ? o : p;   // white
+    }
+    if (!mover_white) p0[G::META_WORD] |= G::META_BIT;   // black moved => white to play
     return 0;
 }
 

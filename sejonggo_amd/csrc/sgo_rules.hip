@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void k_advance_legal(int n, const uint32_t *in
 // k_history_shift: pure streaming move of the 14 history planes (new plane p <- old plane p-1 / p-3, i.e. the
 // reference's shift + pair swap), one thread per 16-B chunk (4-B word when a plane is not a multiple of 16 B):
 // consecutive threads touch consecutive chunks of one record, so every wave instruction covers whole records.
-template <int S>
+template <int S, bool NT = true>
 __device__ __forceinline__ void history_shift_body(int n, long t0, long stride, const uint32_t *in, const int32_t *in_idx,
                                                    const int32_t *colors, uint32_t *out, const int32_t *out_idx) {
     using G = Geo<S>;
@@ -130,14 +130,23 @@ __device__ __forceinline__ void history_shift_body(int n, long t0, long stride, 
         if constexpr (V4) {
             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
             // streamed once: non-temporal loads and stores keep the history move out of the L2 working set
-            u32x4 v0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(s0));
-            u32x4 v1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(s1));
-            u32x4 v2 = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(s2));
-            u32x4 v3 = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(s3));
-            __builtin_nontemporal_store(v0, reinterpret_cast<u32x4 *>(d0));
-            if (b1) __builtin_nontemporal_store(v1, reinterpret_cast<u32x4 *>(d1));
-            if (b2) __builtin_nontemporal_store(v2, reinterpret_cast<u32x4 *>(d2));
-            if (b3) __builtin_nontemporal_store(v3, reinterpret_cast<u32x4 *>(d3));
+            if constexpr (NT) {
+                u32x4 v0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(s0));
+                u32x4 v1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(s1));
+                u32x4 v2 = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(s2));
+                u32x4 v3 = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(s3));
+                __builtin_nontemporal_store(v0, reinterpret_cast<u32x4 *>(d0));
+                if (b1) __builtin_nontemporal_store(v1, reinterpret_cast<u32x4 *>(d1));
+                if (b2) __builtin_nontemporal_store(v2, reinterpret_cast<u32x4 *>(d2));
+                if (b3) __builtin_nontemporal_store(v3, reinterpret_cast<u32x4 *>(d3));
+            } else {
+                u32x4 v0 = *reinterpret_cast<const u32x4 *>(s0), v1 = *reinterpret_cast<const u32x4 *>(s1);
+                u32x4 v2 = *reinterpret_cast<const u32x4 *>(s2), v3 = *reinterpret_cast<const u32x4 *>(s3);
+                *reinterpret_cast<u32x4 *>(d0) = v0;
+                if (b1) *reinterpret_cast<u32x4 *>(d1) = v1;
+                if (b2) *reinterpret_cast<u32x4 *>(d2) = v2;
+                if (b3) *reinterpret_cast<u32x4 *>(d3) = v3;
+            }
         } else {
             uint32_t v0 = *s0, v1 = *s1, v2 = *s2, v3 = *s3;
             *d0 = v0;
@@ -148,11 +157,11 @@ __device__ __forceinline__ void history_shift_body(int n, long t0, long stride, 
     }
 }
 
-template <int S>
+template <int S, bool NT = true>
 __global__ __launch_bounds__(256) void k_history_shift(int n, const int *n_dev, const uint32_t *in, const int32_t *in_idx,
                                                        const int32_t *colors, uint32_t *out, const int32_t *out_idx) {
     if (n_dev) n = *n_dev;
-    history_shift_body<S>(n, (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x, in, in_idx, colors, out,
+    history_shift_body<S, NT>(n, (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x, in, in_idx, colors, out,
                           out_idx);
 }
 
@@ -390,9 +399,15 @@ int launch_advance_split(int S, int n_max, const int *d_n, const uint32_t *d_in,
                                                                                  d_out, d_out_idx, d_legal, d_legal_idx, d_status);
         } else {
             long blocks = ((long)n_max * CPR + 1023) / 1024;
-            if (blocks > 256 * 16) blocks = 256 * 16;
+            if (blocks > 256 * 64) blocks = 256 * 64;
             if (blocks < 1) blocks = 1;
-            k_history_shift<kS><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(n_max, d_n, d_in, d_in_idx, d_colors, d_out, d_out_idx);
+            static const int nt = getenv("SGO_SHIFT_NT") ? atoi(getenv("SGO_SHIFT_NT")) : 1;
+            static const int bs = getenv("SGO_SHIFT_BLOCKS") ? atoi(getenv("SGO_SHIFT_BLOCKS")) : 0;
+            if (bs > 0) blocks = bs;
+            if (nt)
+                k_history_shift<kS, true><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(n_max, d_n, d_in, d_in_idx, d_colors, d_out, d_out_idx);
+            else
+                k_history_shift<kS, false><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(n_max, d_n, d_in, d_in_idx, d_colors, d_out, d_out_idx);
             k_advance_planes<kS><<<dim3(cdiv(n_max, 64)), dim3(64), 0, st>>>(n_max, d_n, d_in, d_in_idx, d_moves, d_colors, d_out,
                                                                              d_out_idx, d_legal, d_legal_idx, d_status);
         }
