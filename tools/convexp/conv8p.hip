@@ -10,6 +10,9 @@
 extern "C" int conv8p_run(int n, int h, int w, const void *x, const void *wgt, const void *bias, const void *skip, void *y,
                           const void *zeros, int iters, float *ms_out) {
     hipStream_t st = 0;
+#ifdef SGO_CONV8P_STAMPS
+    return -9;
+#else
     int rc = sgo_conv8p::launch(n, h, w, x, wgt, bias, skip, y, zeros, st);
     if (rc) return rc;
     if (hipStreamSynchronize(st) != hipSuccess) return -2;
@@ -28,4 +31,14 @@ extern "C" int conv8p_run(int n, int h, int w, const void *x, const void *wgt, c
         hipEventDestroy(e1);
     }
     return hipGetLastError() == hipSuccess ? 0 : -3;
+#endif
 }
+
+#ifdef SGO_CONV8P_STAMPS
+extern "C" int conv8p_stamps(int n, int h, int w, const void *x, const void *wgt, const void *bias, const void *skip, void *y,
+                             const void *zeros, long long *stamps, int warm) {
+    for (int i = 0; i < warm; i++) sgo_conv8p::launch(n, h, w, x, wgt, bias, skip, y, zeros, 0, stamps);
+    sgo_conv8p::launch(n, h, w, x, wgt, bias, skip, y, zeros, 0, stamps);
+    return hipStreamSynchronize(0) == hipSuccess ? 0 : -2;
+}
+#endif
