@@ -2,7 +2,9 @@
 // convolution with bias (+ skip) + ReLU fused (model.py:37-46 of the reference: Conv2D -> BatchNorm (folded) -> [Add]
 // -> ReLU).  NHWC fp16 in/out, weights [K][3][3][C] fp16, fp32 accumulate.  gfx950 only.
 //
-// GEMM view: M = n*h*w output pixels, N = 256 output channels, K = 9 taps x 256 input channels = 36 K-tiles of 64.
+// GEMM view: M = n*h*w output pixels, N = 256 output channels, K = 9 taps x 256 input channels = 36 K-tiles of 64,
+// ordered channel-chunk-major (K-tile kt = chunk kt/9, tap kt%9): the nine taps of one 64-channel chunk re-read the same
+// 128-B slice of the tile's pixel window back to back, so eight of nine reads hit the XCD's L2.
 // One 512-thread workgroup (8 waves = 2 pixel groups x 4 channel groups) per 256 pixels x 256 channels; LDS holds two
 // K-tile buffers of 64 KiB: pixel rows [lo 128 | hi 128] x 128 B and channel rows [lo 128 | hi 128] x 128 B.
 //
@@ -113,13 +115,18 @@ __global__ __launch_bounds__(512) void k_conv8p(const char *__restrict__ xb, con
                 for (int d = 0; d < 2; d++) acc[a][b][c][d] = floatx4{0.f, 0.f, 0.f, 0.f};
     half8 pa[4][2], wlo[2][2], whi[2][2];
 
+#ifdef SGO_C8_NODMA
+#define SGO_GLDS_LOOP(src, ldsoff) asm volatile("" ::"v"(src))
+#else
+#define SGO_GLDS_LOOP(src, ldsoff) SGO_GLDS(src, ldsoff)
+#endif
 #define SGO_GLDS(src, ldsoff) \
     __builtin_amdgcn_global_load_lds((const SGO_AS1 void *)(src), (SGO_AS3 void *)((SGO_AS3 char *)smem + (ldsoff)), 16, 0, 0)
 
 // stage the pixel granule G (0 lo, 1 hi) of K-tile ts into buffer BUF
 #define SGO_STAGE_A(BUF, G, ts)                                                                       \
     do {                                                                                              \
-        const int tap_ = (ts) >> 2, cc_ = (ts) & 3;                                                   \
+        const int cc_ = ((ts) * 57) >> 9, tap_ = (ts) - 9 * cc_;                                      \
         const int dy_ = (tap_ * 11) >> 5, dx_ = tap_ - 3 * dy_;                                       \
         const int toff_ = ((dy_ - 1) * W + (dx_ - 1)) * ROWB + cc_ * 128;                             \
         int ao_ = aoff00;                                                                             \
@@ -127,39 +134,53 @@ __global__ __launch_bounds__(512) void k_conv8p(const char *__restrict__ xb, con
         _Pragma("unroll") for (int i_ = 0; i_ < 2; i_++) {                                            \
             const bool ok_ = (amask[G] >> (9 * i_ + tap_)) & 1;                                       \
             const char *src_ = ok_ ? xb + (unsigned)((ao_ ^ (i_ * 64)) + (i_ * 8 + (G) * 128) * ROWB + toff_) : zb; \
-            SGO_GLDS(src_, (BUF) * 65536 + (G) * 16384 + (wid * 2 + i_) * 1024);                      \
+            SGO_GLDS_LOOP(src_, (BUF) * 65536 + (G) * 16384 + (wid * 2 + i_) * 1024);                      \
         }                                                                                             \
     } while (0)
 // stage the channel granule G of K-tile ts
 #define SGO_STAGE_B(BUF, G, ts)                                                                       \
     do {                                                                                              \
+        const int kc_ = ((ts) * 57) >> 9, koff_ = ((ts) - 9 * kc_) * (CIN * 2) + kc_ * 128;          \
         int bo_ = boff00;                                                                             \
         asm volatile("" : "+v"(bo_));                                                                 \
         _Pragma("unroll") for (int i_ = 0; i_ < 2; i_++) {                                            \
-            const char *src_ = wb + (unsigned)((bo_ ^ (i_ * 64)) + (i_ * 8 + (G) * 128) * WROWB + (ts) * 128); \
-            SGO_GLDS(src_, (BUF) * 65536 + 32768 + (G) * 16384 + (wid * 2 + i_) * 1024);              \
+            const char *src_ = wb + (unsigned)((bo_ ^ (i_ * 64)) + (i_ * 8 + (G) * 128) * WROWB + koff_); \
+            SGO_GLDS_LOOP(src_, (BUF) * 65536 + 32768 + (G) * 16384 + (wid * 2 + i_) * 1024);              \
         }                                                                                             \
     } while (0)
 #define SGO_LDS16(off) (*reinterpret_cast<const half8 *>(smem + (off)))
+#ifdef SGO_C8_NOREAD
+#define SGO_LDS16_LOOP(off) (__builtin_bit_cast(half8, intx4{rdA0, rdB0, (int)(off), rdA1}))
+#else
+#define SGO_LDS16_LOOP(off) SGO_LDS16(off)
+#endif
 #define SGO_READ_A(BUF, G)                                                                            \
     _Pragma("unroll") for (int mt_ = 0; mt_ < 4; mt_++) {                                             \
-        pa[mt_][0] = SGO_LDS16((BUF) * 65536 + (G) * 16384 + mt_ * 2048 + rdA0);                      \
-        pa[mt_][1] = SGO_LDS16((BUF) * 65536 + (G) * 16384 + mt_ * 2048 + rdA1);                      \
+        pa[mt_][0] = SGO_LDS16_LOOP((BUF) * 65536 + (G) * 16384 + mt_ * 2048 + rdA0);                      \
+        pa[mt_][1] = SGO_LDS16_LOOP((BUF) * 65536 + (G) * 16384 + mt_ * 2048 + rdA1);                      \
     }
 #define SGO_READ_B(BUF, G, dst)                                                                       \
     _Pragma("unroll") for (int nt_ = 0; nt_ < 2; nt_++) {                                             \
-        dst[nt_][0] = SGO_LDS16((BUF) * 65536 + 32768 + (G) * 16384 + nt_ * 2048 + rdB0);             \
-        dst[nt_][1] = SGO_LDS16((BUF) * 65536 + 32768 + (G) * 16384 + nt_ * 2048 + rdB1);             \
+        dst[nt_][0] = SGO_LDS16_LOOP((BUF) * 65536 + 32768 + (G) * 16384 + nt_ * 2048 + rdB0);             \
+        dst[nt_][1] = SGO_LDS16_LOOP((BUF) * 65536 + 32768 + (G) * 16384 + nt_ * 2048 + rdB1);             \
     }
 #define SGO_SYNC_IN()                                 \
     __builtin_amdgcn_s_barrier();                     \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
     __builtin_amdgcn_sched_barrier(0);                \
     __builtin_amdgcn_s_setprio(1)
+#ifdef SGO_C8_NOMFMA   // ablation: fragments kept live, no matrix work
+#define SGO_MFMA(QM, QN, wfrag)                                                                        \
+    _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ks_++) {                                              \
+        _Pragma("unroll") for (int mt_ = 0; mt_ < 4; mt_++) asm volatile("" ::"v"(pa[mt_][ks_]));      \
+        _Pragma("unroll") for (int nt_ = 0; nt_ < 2; nt_++) asm volatile("" ::"v"(wfrag[nt_][ks_]));   \
+    }
+#else
 #define SGO_MFMA(QM, QN, wfrag)                                                                        \
     _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ks_++) _Pragma("unroll") for (int mt_ = 0; mt_ < 4; mt_++) \
         _Pragma("unroll") for (int nt_ = 0; nt_ < 2; nt_++) acc[QM][QN][mt_][nt_] =                    \
             __builtin_amdgcn_mfma_f32_16x16x32_f16(wfrag[nt_][ks_], pa[mt_][ks_], acc[QM][QN][mt_][nt_], 0, 0, 0)
+#endif
 #define SGO_SYNC_OUT()                 \
     __builtin_amdgcn_s_setprio(0);     \
     __builtin_amdgcn_sched_barrier(0); \

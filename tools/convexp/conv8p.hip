@@ -5,12 +5,27 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#ifdef USE_CONV8W
+#include "../../sejonggo_amd/csrc/sgo_conv8w.hpp"
+namespace sgo_conv8p {
+#ifdef SGO_CONV8_STAMPS
+static inline int launch(int n, int h, int w, const void *x, const void *wgt, const void *bias, const void *skip, void *y, const void *, hipStream_t st, long long *stamps) {
+    return sgo_conv8w::launch(n, h, w, x, wgt, bias, skip, y, st, stamps);
+}
+#else
+static inline int launch(int n, int h, int w, const void *x, const void *wgt, const void *bias, const void *skip, void *y, const void *, hipStream_t st) {
+    return sgo_conv8w::launch(n, h, w, x, wgt, bias, skip, y, st);
+}
+#endif
+}
+#else
 #include "../../sejonggo_amd/csrc/sgo_conv8p.hpp"
+#endif
 
 extern "C" int conv8p_run(int n, int h, int w, const void *x, const void *wgt, const void *bias, const void *skip, void *y,
                           const void *zeros, int iters, float *ms_out) {
     hipStream_t st = 0;
-#ifdef SGO_CONV8P_STAMPS
+#if defined(SGO_CONV8P_STAMPS) || defined(SGO_CONV8_STAMPS)
     return -9;
 #else
     int rc = sgo_conv8p::launch(n, h, w, x, wgt, bias, skip, y, zeros, st);
@@ -34,7 +49,7 @@ extern "C" int conv8p_run(int n, int h, int w, const void *x, const void *wgt, c
 #endif
 }
 
-#ifdef SGO_CONV8P_STAMPS
+#if defined(SGO_CONV8P_STAMPS) || defined(SGO_CONV8_STAMPS)
 extern "C" int conv8p_stamps(int n, int h, int w, const void *x, const void *wgt, const void *bias, const void *skip, void *y,
                              const void *zeros, long long *stamps, int warm) {
     for (int i = 0; i < warm; i++) sgo_conv8p::launch(n, h, w, x, wgt, bias, skip, y, zeros, 0, stamps);

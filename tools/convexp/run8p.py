@@ -17,13 +17,14 @@ here = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(here, "..", ".."))
 import glob
 LIBS = {os.path.basename(f)[3:-3]: C.CDLL(f) for f in sorted(glob.glob(os.path.join(here, "libconv8p*.so"))) if "stamps" not in f}
-lib = LIBS["conv8p"]
+MAIN = os.environ.get("CONV8_MAIN", "conv8p")
+lib = LIBS[MAIN]
 P = C.c_void_p
 
 
 def run8p(x, w, b, s, y, zeros, h, wd, iters=0, lib=None):
     ms = C.c_float(0)
-    rc = (lib or LIBS["conv8p"]).conv8p_run(x.shape[0], h, wd, P(x.data_ptr()), P(w.data_ptr()), P(b.data_ptr()), P(s.data_ptr()) if s is not None else None,
+    rc = (lib or LIBS[MAIN]).conv8p_run(x.shape[0], h, wd, P(x.data_ptr()), P(w.data_ptr()), P(b.data_ptr()), P(s.data_ptr()) if s is not None else None,
                         P(y.data_ptr()), P(zeros.data_ptr()), iters, C.byref(ms))
     assert rc == 0, rc
     return ms.value
@@ -83,7 +84,7 @@ def main():
                             ms = run8p(x, w, b, s, y, zeros, h, wd, iters=20, lib=l)
                             line += " %s %.3f ms %.0f TF |" % (name, ms, fl / ms / 1e9)
                     ms = run8p(x, w, b, s, y, zeros, h, wd, iters=20)
-                    line += " conv8p %.3f ms %.0f TFLOP/s" % (ms, fl / ms / 1e9)
+                    line += " %s %.3f ms %.0f TFLOP/s" % (MAIN, ms, fl / ms / 1e9)
                     if ck is not None:
                         xs = x
                         st = torch.cuda.current_stream().cuda_stream
