@@ -103,6 +103,14 @@ int sgo_bias_act_dev(long n_elems, int channels, const void *d_x, const void *d_
 int sgo_conv3x3_bias_act_dev(int n, int h, int w, int c, int k, int pad, const void *d_x, const void *d_w,
                              const void *d_bias, const void *d_skip, void *d_y, void *stream);
 
+/* The hand-written CDNA4 kernel for the tower shape (c = k = 256, pad 1, w <= 19; csrc/sgo_conv8w.hpp); the entry
+ * point above dispatches here whenever the shape fits.  Same layouts. */
+int sgo_conv3x3_tower_dev(int n, int h, int w, const void *d_x, const void *d_w, const void *d_bias, const void *d_skip,
+                          void *d_y, void *stream);
+/* Back-end selection of sgo_conv3x3_bias_act_dev: 0 = hand-written kernel where the shape fits (default), 1 = generic
+ * path for every shape (A/B measurements).  Returns the previous mode; any other value only queries. */
+int sgo_conv_backend(int mode);
+
 /* ---- self-play engine: virtual-loss PUCT + game loop, many games resident on one GPU ------------ */
 /* Replaces nomodel_self_play.py:59-82 async_simulate2, :114-140 select_play, :142-271 play_game_async,
  * tree_util.py:4-32, play.py:308-323/376-421, simulation_workers.py:42-54 basic_tasks2 and the request

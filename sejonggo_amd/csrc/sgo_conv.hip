@@ -1,6 +1,12 @@
 // sgo_conv.hip -- the residual tower's 3x3 convolution with the bias / skip / ReLU epilogue fused into the GEMM's
 // output stage, for the resident policy/value net (model.py:37-46 of the reference: Conv2D -> BatchNorm (folded) ->
-// [Add] -> ReLU).  The implicit-GEMM main loop is AMD's composable_kernel xdlops (MFMA) grouped-convolution template,
+// [Add] -> ReLU).
+//
+// Two back ends behind sgo_conv3x3_bias_act_dev:
+//   * sgo_conv8w.hpp -- the hand-written CDNA4 kernel for the tower shape (256 -> 256 channels, 'same' padding, board
+//     width <= 19): sgo_conv3x3_tower_dev.  This is what the 20-block tower runs on.
+//   * the generic fall-through for every other shape (the 32 -> 256 'valid' stem, other channel counts): an
+//     implicit-GEMM main loop from AMD's composable_kernel xdlops (MFMA) grouped-convolution template,
 // instantiated here with a tile found by sweeping on gfx950 (tools/ckexp: 256 threads, 128 pixels x 256 channels,
 // 32x32 MFMA, 2x4 tiles per wave, K step 64 -- the library's own instances all use a K step of 32: 3.17 ms vs
 // 3.54 ms per 8192x256x17x17 convolution for the best of those), and with OUR epilogue functors, so that the separate
@@ -15,6 +21,7 @@
 #include "ck/tensor_operation/gpu/element/element_wise_operation.hpp"
 
 #include "sgo_common.hpp"
+#include "sgo_conv8w.hpp"
 
 namespace {
 
@@ -56,6 +63,41 @@ using Arr5 = std::array<ck::index_t, 5>;
 
 }  // namespace
 
+namespace {
+int g_conv_backend = 0;   // 0: hand-written kernel where the shape fits, 1: generic path only
+}
+
+extern "C" int sgo_conv_backend(int mode) {
+    const int old = g_conv_backend;
+    if (mode == 0 || mode == 1) g_conv_backend = mode;
+    return old;
+}
+
+extern "C" int sgo_conv3x3_tower_dev(int n, int h, int w, const void *d_x, const void *d_w, const void *d_bias,
+                                     const void *d_skip, void *d_y, void *stream) {
+    using namespace sgo;
+    if (n <= 0 || h <= 0 || w <= 0 || w > sgo_conv8w::MAXW || !d_x || !d_w || !d_bias || !d_y) {
+        set_error("sgo_conv3x3_tower_dev: bad argument (256 -> 256 channels, pad 1, board width <= 19)");
+        return SGO_ERR_ARG;
+    }
+    // the kernel addresses pixels with 32-bit byte offsets: batches beyond 2^31 bytes per tensor run in slices
+    const long per = (long)h * w * sgo_conv8w::ROWB;
+    long max_n = ((1L << 31) - 1) / per;
+    if (max_n > 256) max_n -= max_n % 256;
+    if (max_n < 1) { set_error("sgo_conv3x3_tower_dev: one sample exceeds the addressable range"); return SGO_ERR_ARG; }
+    for (long n0 = 0; n0 < n; n0 += max_n) {
+        const int nn = (int)((n - n0 < max_n) ? (n - n0) : max_n);
+        const char *s0 = d_skip ? (const char *)d_skip + n0 * per : nullptr;
+        if (sgo_conv8w::launch(nn, h, w, (const char *)d_x + n0 * per, d_w, d_bias, s0, (char *)d_y + n0 * per,
+                               (hipStream_t)stream) != 0) {
+            set_error("sgo_conv3x3_tower_dev: launch rejected");
+            return SGO_ERR_ARG;
+        }
+    }
+    SGO_HIP(hipGetLastError());
+    return SGO_OK;
+}
+
 extern "C" int sgo_conv3x3_bias_act_dev(int n, int h, int w, int c, int k, int pad, const void *d_x, const void *d_w,
                                         const void *d_bias, const void *d_skip, void *d_y, void *stream) {
     using namespace sgo;
@@ -63,6 +105,8 @@ extern "C" int sgo_conv3x3_bias_act_dev(int n, int h, int w, int c, int k, int p
         set_error("sgo_conv3x3_bias_act_dev: bad argument (channels must be multiples of 8)");
         return SGO_ERR_ARG;
     }
+    if (g_conv_backend == 0 && c == sgo_conv8w::CIN && k == sgo_conv8w::COUT && pad == 1 && w <= sgo_conv8w::MAXW)
+        return sgo_conv3x3_tower_dev(n, h, w, d_x, d_w, d_bias, d_skip, d_y, stream);
     const int ho = h + 2 * pad - 2, wo = w + 2 * pad - 2;
     if (ho <= 0 || wo <= 0) { set_error("sgo_conv3x3_bias_act_dev: empty output"); return SGO_ERR_ARG; }
     // the instance addresses tensors with 32-bit element offsets: run batches whose tensors exceed 2^31 bytes in slices

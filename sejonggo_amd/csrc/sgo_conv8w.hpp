@@ -16,14 +16,14 @@
 // * Staging is LDS-DMA only (global_load_lds_dwordx4); one wave instruction fills 8 rows x 128 B.  LDS images are
 //   XOR-swizzled on the SOURCE side: window chunk c of row r sits at c ^ (r & 7) (conflict-free for the b128 lane
 //   groups of MI355X_MICROARCH.md at EVERY row shift), weight chunk c of row r at c ^ ((r >> 1) & 7).
-// * Schedule: 4 phases per K-tile, each { fragment reads | DMA issue | counted vmcnt | barrier | 16 MFMA | barrier };
-//   the two pixel groups run one barrier apart, so on every SIMD one wave issues MFMAs while its partner reads LDS:
-//        phase 1: read pixel-lo (window) + chan-lo | stage chan-hi[t+1] | vmcnt(4): chan-hi[t] | MFMA (lo,lo)
-//        phase 2: read chan-hi                     |                    |                      | MFMA (lo,hi)
-//        phase 3: read pixel-hi (window)           | stage chan-lo[t+2] |                      | MFMA (hi,hi)
-//        phase 4: vmcnt(4): chan-lo[t+1]           | window piece of the next chunk (taps 0..4) | MFMA (hi,lo)
-//   Every region is re-staged at least two barrier intervals after its last read and read one phase after the wait
-//   that retires it; the counts are exact without a window piece in flight and conservative (older only) with one.
+// * Schedule: 2 phases per K-tile, each { fragment reads | DMA issue | counted vmcnt | lgkmcnt(0) | barrier | 32 MFMA |
+//   barrier }; the two pixel groups run one barrier apart, so on every SIMD one wave issues MFMAs while its partner
+//   reads LDS (intervals of 32 MFMAs = 512 cycles amortise the barrier and the partner's interference better than 16):
+//        phase A: read chan-lo, chan-hi, pixel-lo (window)                                   | MFMA (lo,lo) (lo,hi)
+//        phase B: read pixel-hi (window) | stage weights[t+2], window piece of the next chunk | MFMA (hi,hi) (hi,lo)
+//   A wave retires its own LDS reads before the barrier that ends its read interval, so a region may be re-staged from
+//   the next interval on; staged data is read one phase after the counted wait that retires it (weights[t+1] are waited
+//   for in phase B of K-tile t with exactly the younger DMAs left in flight: never vmcnt(0) in the loop).
 // * MFMA: v_mfma_f32_16x16x32_f16 with the WEIGHTS as the row operand, so a lane ends up with 4 consecutive output
 //   channels of one pixel.
 // * Epilogue through LDS: the skip rows arrive by DMA (lo half behind the last K-tile, hi half behind the lo half's
@@ -64,7 +64,7 @@ constexpr int LW0 = 0, LB0 = 40960, LB1 = 73728, LW1 = 106496, LZ = 147456, LDS_
 template <bool HAS_SKIP>
 __global__ __launch_bounds__(512) void k_conv8w(const char *__restrict__ xb, const char *__restrict__ wb,
                                                  const _Float16 *__restrict__ bias, const char *__restrict__ skipb,
-                                                 char *__restrict__ yb, int M, int H, int W
+                                                 char *__restrict__ yb, int M, int H, int W, unsigned magicHW, unsigned magicW
 #ifdef SGO_CONV8_STAMPS
                                                  , long long *stamps
 #endif
@@ -81,28 +81,6 @@ __global__ __launch_bounds__(512) void k_conv8w(const char *__restrict__ xb, con
 
     if (tid < 8) *reinterpret_cast<intx4 *>(smem + LZ + tid * 16) = intx4{0, 0, 0, 0};
 
-    // ---- tap-validity masks of the lane's 8 fragment rows: row (G, mt) = G*128 + wr*64 + mt*16 + (lane&15);
-    //      mk[G][mt>>1] holds 9 bits per row at bit (mt&1)*9
-    int mk[2][2];
-#pragma unroll
-    for (int g = 0; g < 2; g++)
-#pragma unroll
-        for (int h2 = 0; h2 < 2; h2++) {
-            int v = 0;
-#pragma unroll
-            for (int e = 0; e < 2; e++) {
-                const int p = tile * 256 + g * 128 + wr * 64 + (h2 * 2 + e) * 16 + (lane & 15);
-                const int q = p % HW, yy = q / W, xx = q - yy * W;
-                int m = 0;
-#pragma unroll
-                for (int t = 0; t < 9; t++) {
-                    const int y2 = yy + t / 3 - 1, x2 = xx + t % 3 - 1;
-                    if (p < M && y2 >= 0 && y2 < H && x2 >= 0 && x2 < W) m |= 1 << t;
-                }
-                v |= m << (9 * e);
-            }
-            mk[g][h2] = v;
-        }
     // ---- weight staging: instruction i of this wave fills rows (wid*2+i)*8 + (lane>>3) of a 128-row granule, 16-B
     //      chunk (lane&7) ^ swizzle; offsets of (granule, i) differ from (0, 0) by constants and one XOR
     const int boff00 = (wid * 16 + (lane >> 3)) * WROWB + (((lane & 7) ^ (lane >> 4)) << 4);
@@ -173,10 +151,13 @@ __global__ __launch_bounds__(512) void k_conv8w(const char *__restrict__ xb, con
         dst[nt_][0] = SGW_LDS16(((BUF) ? LB1 : LB0) + (G) * 16384 + nt_ * 2048 + rdB0);               \
         dst[nt_][1] = SGW_LDS16(((BUF) ? LB1 : LB0) + (G) * 16384 + nt_ * 2048 + rdB1);               \
     }
-#define SGW_SYNC_IN()                                 \
-    __builtin_amdgcn_s_barrier();                     \
+// end of a read/stage interval: own LDS reads retired BEFORE the barrier, so the partner group may re-stage what was
+// read from the very next interval on
+#define SGW_SYNC_IN()                                  \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
-    __builtin_amdgcn_sched_barrier(0);                \
+    __builtin_amdgcn_sched_barrier(0);                 \
+    __builtin_amdgcn_s_barrier();                      \
+    __builtin_amdgcn_sched_barrier(0);                 \
     __builtin_amdgcn_s_setprio(1)
 #define SGW_MFMA(QM, QN, wfrag)                                                                        \
     _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ks_++) _Pragma("unroll") for (int mt_ = 0; mt_ < 4; mt_++) \
@@ -186,49 +167,76 @@ __global__ __launch_bounds__(512) void k_conv8w(const char *__restrict__ xb, con
     __builtin_amdgcn_s_setprio(0);     \
     __builtin_amdgcn_sched_barrier(0); \
     __builtin_amdgcn_s_barrier()
-
-// one K-tile t, weights in buffer BUF; S1 / S3: whether K-tiles t+1 / t+2 exist; W1, W4: vmcnt of phases 1 and 4;
-// EXTRA(ph): additional DMA issued in phase ph (skip rows behind the last K-tile)
-#define SGW_TILE(BUF, t, S1, S3, W1, W4, EXTRA)         \
-    do {                                                \
-        SGW_READ_B(BUF, 0, wlo);                        \
-        __builtin_amdgcn_sched_barrier(0);              \
-        SGW_READ_A(0, t);                               \
-        if (S1) SGW_STAGE_B((BUF) ^ 1, 1, (t) + 1);     \
-        EXTRA(0);                                       \
-        SGW_VMWAIT(W1); /* chan-hi[t] */                \
-        SGW_SYNC_IN();                                  \
-        SGW_MFMA(0, 0, wlo);                            \
-        SGW_SYNC_OUT();                                 \
-        SGW_READ_B(BUF, 1, whi);                        \
-        EXTRA(1);                                       \
-        SGW_SYNC_IN();                                  \
-        SGW_MFMA(0, 1, whi);                            \
-        SGW_SYNC_OUT();                                 \
-        SGW_READ_A(1, t);                               \
-        if (S3) SGW_STAGE_B(BUF, 0, (t) + 2);           \
-        EXTRA(2);                                       \
-        SGW_SYNC_IN();                                  \
-        SGW_MFMA(1, 1, whi);                            \
-        SGW_SYNC_OUT();                                 \
-        SGW_VMWAIT(W4); /* chan-lo[t+1] */              \
-        if (S3) {                                       \
-            const int c4_ = ((t) * 57) >> 9, t4_ = (t) - 9 * c4_; \
-            if (t4_ < 5 && c4_ < 3) SGW_STAGE_W(c4_ + 1, t4_);    \
-        }                                               \
-        EXTRA(3);                                       \
-        SGW_SYNC_IN();                                  \
-        SGW_MFMA(1, 0, wlo);                            \
-        SGW_SYNC_OUT();                                 \
+// counted wait of phase B: retires the weights of K-tile t+1 (4 DMAs issued one K-tile ago); younger than those are the
+// window piece of the previous K-tile, the 4 weight DMAs and the window piece of this one
+#define SGW_WAIT_B(nyoung)                     \
+    do {                                       \
+        if ((nyoung) == 4) SGW_VMWAIT(4);      \
+        else if ((nyoung) == 5) SGW_VMWAIT(5); \
+        else SGW_VMWAIT(6);                    \
     } while (0)
 
-    // ---- prologue: window of chunk 0, K-tile 0's weights; chan-lo of K-tile 1 stays in flight
+// one K-tile t, weights in buffer BUF, two phases of 32 MFMAs.  S2: whether K-tile t+2 exists (its weights are staged in
+// phase B into this tile's buffer, whose reads were retired in phase A); LASTW: wait used instead when nothing is staged
+// (0 = drain, 63 = none); EXTRA(ph): additional DMA (skip rows behind the last K-tile)
+#define SGW_TILE(BUF, t, S2, LASTW, EXTRA)                                                   \
+    do {                                                                                     \
+        const int cA_ = ((t) * 57) >> 9, tA_ = (t) - 9 * cA_;                                \
+        SGW_READ_B(BUF, 0, wlo);                                                             \
+        SGW_READ_B(BUF, 1, whi);                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        SGW_READ_A(0, t);                                                                    \
+        EXTRA(0);                                                                            \
+        SGW_SYNC_IN();                                                                       \
+        SGW_MFMA(0, 0, wlo);                                                                 \
+        SGW_MFMA(0, 1, whi);                                                                 \
+        SGW_SYNC_OUT();                                                                      \
+        SGW_READ_A(1, t);                                                                    \
+        if (S2) {                                                                            \
+            SGW_STAGE_B(BUF, 0, (t) + 2);                                                    \
+            SGW_STAGE_B(BUF, 1, (t) + 2);                                                    \
+            const bool wp_ = cA_ < 3 && tA_ < 5, wpprev_ = cA_ < 3 && tA_ >= 1 && tA_ <= 5;  \
+            if (wp_) SGW_STAGE_W(cA_ + 1, tA_);                                              \
+            SGW_WAIT_B(4 + (wp_ ? 1 : 0) + (wpprev_ ? 1 : 0));                               \
+        } else {                                                                             \
+            EXTRA(1);                                                                        \
+            SGW_VMWAIT(LASTW);                                                               \
+        }                                                                                    \
+        SGW_SYNC_IN();                                                                       \
+        SGW_MFMA(1, 1, whi);                                                                 \
+        SGW_MFMA(1, 0, wlo);                                                                 \
+        SGW_SYNC_OUT();                                                                      \
+    } while (0)
+
+    // ---- prologue: window of chunk 0, K-tile 0's weights; K-tile 1's weights stay in flight
 #pragma unroll
     for (int pc = 0; pc < 5; pc++) SGW_STAGE_W(0, pc);
     SGW_STAGE_B(0, 0, 0);
     SGW_STAGE_B(0, 1, 0);
     SGW_STAGE_B(1, 0, 1);
-    SGW_VMWAIT(2);
+    SGW_STAGE_B(1, 1, 1);
+    // ---- tap-validity masks of the lane's 8 fragment rows: row (G, mt) = G*128 + wr*64 + mt*16 + (lane&15);
+    //      mk[G][mt>>1] holds 9 bits per row at bit (mt&1)*9.  Divisions by h*w and w through the host's magic numbers
+    //      (ceil(2^32/d): exact for p*d < 2^32).
+    int mk[2][2];
+#pragma unroll
+    for (int g = 0; g < 2; g++)
+#pragma unroll
+        for (int h2 = 0; h2 < 2; h2++) {
+            int v = 0;
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const int p = tile * 256 + g * 128 + wr * 64 + (h2 * 2 + e) * 16 + (lane & 15);
+                const int q = p - (int)__umulhi((unsigned)p, magicHW) * HW;
+                const int yy = (int)__umulhi((unsigned)q, magicW), xx = q - yy * W;
+                const int cm = (xx >= 1 ? 1 : 0) | 2 | (xx <= W - 2 ? 4 : 0);
+                int m = (yy >= 1 ? cm : 0) | (cm << 3) | (yy <= H - 2 ? cm << 6 : 0);
+                m = p < M ? m : 0;
+                v |= m << (9 * e);
+            }
+            mk[g][h2] = v;
+        }
+    SGW_VMWAIT(4);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the zero row
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();   // the hi pixel group runs one barrier behind
@@ -246,19 +254,20 @@ __global__ __launch_bounds__(512) void k_conv8w(const char *__restrict__ xb, con
         SGW_GLDS(skipb + (unsigned)(p_ * ROWB + (((elane & 31) ^ (r_ & 15)) << 4)), (HF) * 65536 + (wid * 8 + (j)) * 1024); \
     } while (0)
 #define SGW_NOEXTRA(ph) do { } while (0)
-#define SGW_SKIP_LO(ph) do { SGW_STAGE_SKIP(0, 2 * (ph)); SGW_STAGE_SKIP(0, 2 * (ph) + 1); } while (0)
+#define SGW_SKIP_LO(ph) \
+    do { SGW_STAGE_SKIP(0, 4 * (ph)); SGW_STAGE_SKIP(0, 4 * (ph) + 1); SGW_STAGE_SKIP(0, 4 * (ph) + 2); SGW_STAGE_SKIP(0, 4 * (ph) + 3); } while (0)
 
     for (int t = 0; t < NTILE - 2; t += 2) {
-        SGW_TILE(0, t, true, true, 4, 4, SGW_NOEXTRA);
-        SGW_TILE(1, t + 1, true, true, 4, 4, SGW_NOEXTRA);
+        SGW_TILE(0, t, true, 0, SGW_NOEXTRA);
+        SGW_TILE(1, t + 1, true, 0, SGW_NOEXTRA);
     }
-    SGW_TILE(0, NTILE - 2, true, false, 4, 2, SGW_NOEXTRA);
+    SGW_TILE(0, NTILE - 2, false, 0, SGW_NOEXTRA);   // drain: K-tile 35's weights
     int elane = lane;   // opaque copy: keeps the epilogue's address arithmetic from being hoisted above the main loop
     asm volatile("" : "+v"(elane));
     // the last K-tile has nothing to stage: its DMA slots carry the lo half of the skip tile into [0, 64 KiB) (window
     // buffer 0 and weight buffer 0, idle since K-tile 34)
-    if constexpr (HAS_SKIP) SGW_TILE(1, NTILE - 1, false, false, 2, 63, SGW_SKIP_LO);
-    else SGW_TILE(1, NTILE - 1, false, false, 0, 63, SGW_NOEXTRA);
+    if constexpr (HAS_SKIP) SGW_TILE(1, NTILE - 1, false, 63, SGW_SKIP_LO);
+    else SGW_TILE(1, NTILE - 1, false, 63, SGW_NOEXTRA);
     if (wr == 0) __builtin_amdgcn_s_barrier();
 #ifdef SGO_CONV8_STAMPS
     const long long st2 = __builtin_amdgcn_s_memtime();
@@ -368,10 +377,11 @@ static inline int launch(int n, int h, int w, const void *x, const void *wgt, co
     const long M = (long)n * h * w;
     if (M <= 0 || M * ROWB >= (1L << 31) || w > MAXW || w < 1 || h < 1) return -1;
     const int tiles = (int)((M + 255) / 256);
+    const unsigned mhw = (unsigned)(((1ULL << 32) + (unsigned)(h * w) - 1) / (unsigned)(h * w)), mw = (unsigned)(((1ULL << 32) + (unsigned)w - 1) / (unsigned)w);
 #ifdef SGO_CONV8_STAMPS
-#define SGW_ARGS (const char *)x, (const char *)wgt, (const _Float16 *)bias, (const char *)skip, (char *)y, (int)M, h, w, stamps
+#define SGW_ARGS (const char *)x, (const char *)wgt, (const _Float16 *)bias, (const char *)skip, (char *)y, (int)M, h, w, mhw, mw, stamps
 #else
-#define SGW_ARGS (const char *)x, (const char *)wgt, (const _Float16 *)bias, (const char *)skip, (char *)y, (int)M, h, w
+#define SGW_ARGS (const char *)x, (const char *)wgt, (const _Float16 *)bias, (const char *)skip, (char *)y, (int)M, h, w, mhw, mw
 #endif
     if (skip) hipLaunchKernelGGL(k_conv8w<true>, dim3(tiles), dim3(512), 0, st, SGW_ARGS);
     else hipLaunchKernelGGL(k_conv8w<false>, dim3(tiles), dim3(512), 0, st, SGW_ARGS);
