@@ -9,8 +9,8 @@
 // What makes it a convolution kernel rather than a GEMM on an im2col view: the PIXEL WINDOW.  The nine taps of one
 // 64-channel chunk read the same 256 + 2(w+1) pixel rows, shifted by (dy-1)*w + (dx-1).  The window slice (<= 320 rows
 // x 128 B) is brought into LDS once per chunk (double-buffered over chunks) and every tap's fragments are ds_read from
-// it at a shifted row; a tap that falls off the board reads a 128-B zero row instead (per-row 9-bit masks, one
-// v_cndmask on the address).  Global -> LDS traffic per workgroup drops from 2 x 32 KiB per K-tile to 32 KiB of weights
+// it at a shifted row; a tap that falls off the board reads zeros instead (per-row 9-bit masks, one v_cndmask on the
+// address; the zero area mirrors the bank slot of the address it replaces, so the redirect adds no bank conflict).  Global -> LDS traffic per workgroup drops from 2 x 32 KiB per K-tile to 32 KiB of weights
 // + 4.4 KiB of window, which is what bounds a 256 x 256 tile on this chip (L2 -> LDS gather rate, not MFMA rate).
 //
 // * Staging is LDS-DMA only (global_load_lds_dwordx4); one wave instruction fills 8 rows x 128 B.  LDS images are
@@ -49,7 +49,7 @@ constexpr int ROWB = CIN * 2;        // bytes per pixel row of x / y
 constexpr int WROWB = 9 * CIN * 2;   // bytes per output channel of the weights
 constexpr int MAXW = 19;             // board width limit (window = 256 + 2 (w + 1) <= 296 of 320 rows)
 // LDS map
-constexpr int LW0 = 0, LB0 = 40960, LB1 = 73728, LW1 = 106496, LZ = 147456, LDS_BYTES = 147584;
+constexpr int LW0 = 0, LB0 = 40960, LB1 = 73728, LW1 = 106496, LZ = 147456, LZ_BYTES = 3 * 2048 + 256, LDS_BYTES = LZ + LZ_BYTES;
 
 // LDS accesses the compiler must not order against in-flight LDS-DMA (it would drain vmcnt to 0 before each of its own
 // ds_read once a DMA is pending): issued as asm, waited for by hand (SGW_LGKM0 = lgkmcnt(0) + a scheduling fence).
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(512) void k_conv8w(const char *__restrict__ xb, con
     const int tile = blockIdx.x;
     const int HW = H * W, HALO = W + 1, NROWS = 256 + 2 * HALO;
 
-    if (tid < 8) *reinterpret_cast<intx4 *>(smem + LZ + tid * 16) = intx4{0, 0, 0, 0};
+    if (tid < LZ_BYTES / 16) *reinterpret_cast<intx4 *>(smem + LZ + tid * 16) = intx4{0, 0, 0, 0};
 
     // ---- weight staging: instruction i of this wave fills rows (wid*2+i)*8 + (lane>>3) of a 128-row granule, 16-B
     //      chunk (lane&7) ^ swizzle; offsets of (granule, i) differ from (0, 0) by constants and one XOR
@@ -137,13 +137,15 @@ __global__ __launch_bounds__(512) void k_conv8w(const char *__restrict__ xb, con
         const int cc_ = ((t) * 57) >> 9, tap_ = (t) - 9 * cc_;                                        \
         const int dy_ = (tap_ * 11) >> 5, dx_ = tap_ - 3 * dy_;                                       \
         const int rl_ = rowA + (dy_ - 1) * W + (dx_ - 1);                                             \
-        const int b0_ = ((cc_ & 1) ? LW1 : LW0) + (rl_ << 7) + ((((lane >> 4) ^ rl_) & 7) << 4);      \
-        const int b1_ = b0_ ^ 64;                                                                     \
+        const int c0_ = (((lane >> 4) ^ rl_) & 7) << 4;                                               \
+        const int b0_ = ((cc_ & 1) ? LW1 : LW0) + (G) * 16384 + (rl_ << 7) + c0_, b1_ = b0_ ^ 64;     \
+        /* an off-board tap reads zeros from the SAME bank slot its window address has (row parity, chunk): no new */ \
+        /* bank conflict with the lanes that do read the window */                                    \
+        const int z0_ = LZ + ((rl_ & 1) << 7) + c0_, z1_ = z0_ ^ 64;                                  \
         _Pragma("unroll") for (int mt_ = 0; mt_ < 4; mt_++) {                                         \
             const bool ok_ = (mk[G][mt_ >> 1] >> ((mt_ & 1) * 9 + tap_)) & 1;                         \
-            const int im_ = (G) * 16384 + mt_ * 2048;                                                 \
-            pa[mt_][0] = SGW_LDS16((ok_ ? b0_ : LZ - im_) + im_);                                     \
-            pa[mt_][1] = SGW_LDS16((ok_ ? b1_ : LZ - im_) + im_);                                     \
+            pa[mt_][0] = SGW_LDS16((ok_ ? b0_ : z0_) + mt_ * 2048);                                   \
+            pa[mt_][1] = SGW_LDS16((ok_ ? b1_ : z1_) + mt_ * 2048);                                   \
         }                                                                                             \
     } while (0)
 #define SGW_READ_B(BUF, G, dst)                                                                       \
