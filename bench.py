@@ -167,6 +167,39 @@ def saturated_advance(S, n=1 << 18, ply=60, iters=10):
             "inputs": "seeded random legal playouts, ply %d" % ply}
 
 
+def tower_conv_roofline(n, side, channels=256, iters=10):
+    """The net's dominant kernel alone: the hand-written tower convolution (csrc/sgo_conv8w.hpp) at the bench's own
+    batch shape, with skip, timed with HIP events on the launch stream.  Inputs are a ReLU'd random activation (what the
+    tower sees) and weights of the scale the folded BatchNorm produces."""
+    import torch
+    from sejonggo_amd import _lib as L
+    lib = L.require_gpu()
+    if channels != 256 or side > 19:
+        return None
+    torch.manual_seed(7)
+    x = torch.relu(torch.randn(n, side, side, 256, device="cuda") * 0.5).half()
+    w = (torch.randn(256, 3, 3, 256, device="cuda") * 0.03).half()
+    b = torch.randn(256, device="cuda").half()
+    s = torch.relu(torch.randn(n, side, side, 256, device="cuda")).half()
+    y = torch.empty_like(s)
+    st = L.stream_ptr()
+    for _ in range(3):
+        L.check(lib.sgo_conv3x3_tower_dev(n, side, side, L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(s), L.ptr(y), st))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        L.check(lib.sgo_conv3x3_tower_dev(n, side, side, L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(s), L.ptr(y), st))
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    fl = 2.0 * n * side * side * 9 * 256 * 256
+    ach = fl / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "k_conv8w<skip> (tower 3x3 convolution 256->256 + bias + skip + ReLU, fp16 in / fp32 accumulate)",
+            "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": None,
+            "flops_per_launch": fl, "avg_launch_ms": ms, "launches": iters,
+            "shape": "n=%d, %dx%d, 256->256" % (n, side, side)}
+
+
 def main():
     args = parse()
     import numpy as np
@@ -288,6 +321,13 @@ def main():
                 out["roofline_saturated"] = saturated_advance(S)
             except Exception as ex:
                 out["roofline_saturated"] = {"error": repr(ex)}
+            if args.net == "resnet" and not args.plain_net:
+                try:
+                    rm = tower_conv_roofline(G * E, S - 2, args.channels)
+                    if rm:
+                        out["roofline_mfma"] = rm
+                except Exception as ex:
+                    out["roofline_mfma"] = {"error": repr(ex)}
         if args.cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(args, S, sims, E, args.blocks, args.channels, args.symmetry)

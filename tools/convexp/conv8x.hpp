@@ -1,4 +1,4 @@
-// sgo_conv8w.hpp -- hand-written MFMA implicit-GEMM kernel for the residual tower's 3x3 / 256 -> 256 'same'
+// sgo_conv8x.hpp -- hand-written MFMA implicit-GEMM kernel for the residual tower's 3x3 / 256 -> 256 'same'
 // convolution with bias (+ skip) + ReLU fused (model.py:37-46 of the reference: Conv2D -> BatchNorm (folded) -> [Add]
 // -> ReLU).  NHWC fp16 in/out, weights [K][3][3][C] fp16, fp32 accumulate.  gfx950 only.
 //
@@ -33,7 +33,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-namespace sgo_conv8w {
+namespace sgo_conv8x {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
@@ -67,9 +67,9 @@ constexpr int LW0 = 0, LB0 = 40960, LB1 = 73728, LW1 = 106496, LZ = 147456, LZ_B
 #define SGW_VMWAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
 template <bool HAS_SKIP>
-__global__ __launch_bounds__(512) void k_conv8w(const char *__restrict__ xb, const char *__restrict__ wb,
+__global__ __launch_bounds__(512) void k_conv8x(const char *__restrict__ xb, const char *__restrict__ wb,
                                                  const _Float16 *__restrict__ bias, const char *__restrict__ skipb,
-                                                 char *__restrict__ yb, int M, int H, int W, unsigned magicHW, unsigned magicW
+                                                 char *__restrict__ yb, int M, int H, int W, unsigned magicHW, unsigned magicW, int ntiles
 #ifdef SGO_CONV8_STAMPS
                                                  , long long *stamps
 #endif
@@ -81,7 +81,6 @@ __global__ __launch_bounds__(512) void k_conv8w(const char *__restrict__ xb, con
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 2, wc = wid & 3;
-    const int tile = blockIdx.x;
     const int HW = H * W, HALO = W + 1, NROWS = 256 + 2 * HALO;
 
     if (tid < LZ_BYTES / 16) *reinterpret_cast<intx4 *>(smem + LZ + tid * 16) = intx4{0, 0, 0, 0};
@@ -97,14 +96,6 @@ __global__ __launch_bounds__(512) void k_conv8w(const char *__restrict__ xb, con
     const int rowA = HALO + wr * 64 + (lane & 15);   // window row of (G = 0, mt = 0) at tap shift 0
 
     floatx4 acc[2][2][4][2];
-#pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-        for (int b = 0; b < 2; b++)
-#pragma unroll
-            for (int c = 0; c < 4; c++)
-#pragma unroll
-                for (int d = 0; d < 2; d++) acc[a][b][c][d] = floatx4{0.f, 0.f, 0.f, 0.f};
     half8 pa[4][2], wlo[2][2], whi[2][2];
 
 #ifdef SGW_NODMA   // ablation build: no DMA inside the K loop
@@ -126,14 +117,15 @@ __global__ __launch_bounds__(512) void k_conv8w(const char *__restrict__ xb, con
             SGW_GLDS_LOOP(src_, ((BUF) ? LB1 : LB0) + (G) * 16384 + (wid * 2 + i_) * 1024);                \
         }                                                                                             \
     } while (0)
+#define SGW_STAGE_W(cc, pc) SGW_STAGE_W_T(cc, pc, tile)
 // stage window piece `pc` (0..4) of channel chunk cc into window buffer (cc & 1): wave wid fills rows (pc*8+wid)*8 ..+7
-#define SGW_STAGE_W(cc, pc)                                                                           \
+#define SGW_STAGE_W_T(cc, pc, TL)                                                                         \
     do {                                                                                              \
         const int id_ = (pc) * 8 + wid;                                                               \
         if (id_ * 8 < NROWS) {                                                                        \
             int la_ = lane;                                                                           \
             asm volatile("" : "+v"(la_));                                                             \
-            int q_ = tile * 256 - HALO + id_ * 8 + (la_ >> 3);                                        \
+            int q_ = (TL) * 256 - HALO + id_ * 8 + (la_ >> 3);                                        \
             q_ = q_ < 0 ? 0 : (q_ < M ? q_ : M - 1);                                                  \
             const char *src_ = xb + (unsigned)(q_ * ROWB + (cc) * 128 + wsrc);                        \
             SGW_GLDS_LOOP(src_, (((cc) & 1) ? LW1 : LW0) + id_ * 1024);                                    \
@@ -239,13 +231,25 @@ __global__ __launch_bounds__(512) void k_conv8w(const char *__restrict__ xb, con
         SGW_SYNC_OUT();                                                                      \
     } while (0)
 
-    // ---- prologue: window of chunk 0, K-tile 0's weights; K-tile 1's weights stay in flight
+    // ---- persistent tile loop: workgroup b runs tiles b, b + grid, ...; the DMA of a tile's first window and weights is
+    //      issued from inside the previous tile's epilogue (first tile: here)
+    int tile = blockIdx.x;
 #pragma unroll
     for (int pc = 0; pc < 5; pc++) SGW_STAGE_W(0, pc);
     SGW_STAGE_B(0, 0, 0);
     SGW_STAGE_B(0, 1, 0);
     SGW_STAGE_B(1, 0, 1);
     SGW_STAGE_B(1, 1, 1);
+    bool first = true;
+    for (;;) {
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+#pragma unroll
+                for (int d = 0; d < 2; d++) acc[a][b][c][d] = floatx4{0.f, 0.f, 0.f, 0.f};
     // ---- tap-validity masks of the lane's 8 fragment rows: row (G, mt) = G*128 + wr*64 + mt*16 + (lane&15);
     //      mk[G][mt>>1] holds 9 bits per row at bit (mt&1)*9.  Divisions by h*w and w through the host's magic numbers
     //      (ceil(2^32/d): exact for p*d < 2^32).
@@ -267,7 +271,10 @@ __global__ __launch_bounds__(512) void k_conv8w(const char *__restrict__ xb, con
             }
             mk[g][h2] = v;
         }
-    SGW_VMWAIT(4);
+    // window 0 and K-tile 0's weights landed: K-tile 1's weights (4 DMAs), and behind a previous tile also its 8 hi-half row
+    // stores, may stay in flight
+    if (first) SGW_VMWAIT(4);
+    else SGW_VMWAIT(12);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the zero row
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();   // the hi pixel group runs one barrier behind
@@ -282,7 +289,7 @@ __global__ __launch_bounds__(512) void k_conv8w(const char *__restrict__ xb, con
         const int r_ = (wid * 8 + (j)) * 2 + (elane >> 5);                                             \
         int p_ = tile * 256 + (HF) * 128 + r_;                                                         \
         p_ = p_ < M ? p_ : M - 1;                                                                      \
-        SGW_GLDS(skipb + (unsigned)(p_ * ROWB + (((elane & 31) ^ (r_ & 15)) << 4)), (HF) * 65536 + (wid * 8 + (j)) * 1024); \
+        SGW_GLDS(skipb + (unsigned)(p_ * ROWB + (((elane & 31) ^ (r_ & 15)) << 4)), ((HF) ? LB1 : 0) + (wid * 8 + (j)) * 1024); \
     } while (0)
 #define SGW_NOEXTRA(ph) do { } while (0)
 #define SGW_SKIP_LO(ph) \
@@ -293,6 +300,7 @@ __global__ __launch_bounds__(512) void k_conv8w(const char *__restrict__ xb, con
         SGW_TILE(1, t + 1, true, 0, SGW_NOEXTRA);
     }
     SGW_TILE(0, NTILE - 2, false, 0, SGW_NOEXTRA);   // drain: K-tile 35's weights
+    const bool has_next = tile + (int)gridDim.x < ntiles;
     int elane = lane;   // opaque copy: keeps the epilogue's address arithmetic from being hoisted above the main loop
     asm volatile("" : "+v"(elane));
     // the last K-tile has nothing to stage: its DMA slots carry the lo half of the skip tile into [0, 64 KiB) (window
@@ -324,17 +332,25 @@ __global__ __launch_bounds__(512) void k_conv8w(const char *__restrict__ xb, con
     const int epc = ((wc * 4 + (elane >> 5)) ^ (elane & 15)) << 4;
 #pragma unroll
     for (int hf = 0; hf < 2; hf++) {
-        const int a0 = hf * 65536 + epx + epc, a1 = hf * 65536 + epx + (epc ^ 32);   // nt = 0 / 1
+        const int ebase = hf ? LB1 : 0;
+        const int a0 = ebase + epx + epc, a1 = ebase + epx + (epc ^ 32);   // nt = 0 / 1
         intx2 sk[4][2][2];
         if (!HAS_SKIP && hf == 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the bias
             __builtin_amdgcn_sched_barrier(0);
         }
+        // own skip DMAs of this half have landed once at most the 8 younger operations (the other half's DMAs, or the 8 row
+        // stores of half 0) are outstanding; the barrier publishes everyone's and, for hf = 1, certifies that every wave has
+        // read its rows of half 0 out of LDS, so the next tile's window and first weights may be staged over them
+        if constexpr (HAS_SKIP) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (HAS_SKIP || (hf == 1 && has_next)) __builtin_amdgcn_s_barrier();
+        if (hf == 1 && has_next) {
+#pragma unroll
+            for (int pc = 0; pc < 5; pc++) SGW_STAGE_W_T(0, pc, tile + (int)gridDim.x);
+            SGW_STAGE_B(0, 0, 0);
+            SGW_STAGE_B(0, 1, 0);
+        }
         if constexpr (HAS_SKIP) {
-            // own DMAs of this half have landed once at most the 8 younger operations (the other half's DMAs, or the 8
-            // row stores of half 0) are outstanding; the barrier publishes everyone's
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
 #pragma unroll
             for (int mt = 0; mt < 4; mt++)
 #pragma unroll
@@ -369,7 +385,7 @@ __global__ __launch_bounds__(512) void k_conv8w(const char *__restrict__ xb, con
         SGW_LGKM0();
         __builtin_amdgcn_s_barrier();
         intx4 ov[8];
-        const int a2 = hf * 65536 + wid * 8192 + elane * 16;
+        const int a2 = ebase + wid * 8192 + elane * 16;
 #pragma unroll
         for (int j = 0; j < 8; j++) SGW_DS_READ128(ov[j], a2, j * 1024);
         const int p0 = tile * 256 + hf * 128 + wid * 16 + (elane >> 5);
@@ -386,11 +402,19 @@ __global__ __launch_bounds__(512) void k_conv8w(const char *__restrict__ xb, con
                     *reinterpret_cast<intx4 *>(dst + j * 2 * ROWB + (((elane & 31) ^ (j * 2 + (elane >> 5))) << 4)) = ov[j];
         }
     }
+    if (!has_next) break;
+    // every wave has read its rows of half 1 out of LDS: K-tile 1's weights of the next tile go over them
+    __builtin_amdgcn_s_barrier();
+    tile += gridDim.x;
+    first = false;
+    SGW_STAGE_B(1, 0, 1);
+    SGW_STAGE_B(1, 1, 1);
+    }
 #ifdef SGO_CONV8_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const long long st3 = __builtin_amdgcn_s_memtime();
     if (lane == 0) {
-        long long *o = stamps + ((size_t)tile * 8 + wid) * 6;
+        long long *o = stamps + ((size_t)blockIdx.x * 8 + wid) * 6;
         o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3; o[4] = __builtin_amdgcn_s_memrealtime();
         o[5] = 0;
     }
@@ -410,14 +434,17 @@ static inline int launch(int n, int h, int w, const void *x, const void *wgt, co
     const int tiles = (int)((M + 255) / 256);
     const unsigned mhw = (unsigned)(((1ULL << 32) + (unsigned)(h * w) - 1) / (unsigned)(h * w)), mw = (unsigned)(((1ULL << 32) + (unsigned)w - 1) / (unsigned)w);
 #ifdef SGO_CONV8_STAMPS
-#define SGW_ARGS (const char *)x, (const char *)wgt, (const _Float16 *)bias, (const char *)skip, (char *)y, (int)M, h, w, mhw, mw, stamps
+#define SGW_ARGS (const char *)x, (const char *)wgt, (const _Float16 *)bias, (const char *)skip, (char *)y, (int)M, h, w, mhw, mw, tiles, stamps
 #else
-#define SGW_ARGS (const char *)x, (const char *)wgt, (const _Float16 *)bias, (const char *)skip, (char *)y, (int)M, h, w, mhw, mw
+#define SGW_ARGS (const char *)x, (const char *)wgt, (const _Float16 *)bias, (const char *)skip, (char *)y, (int)M, h, w, mhw, mw, tiles
 #endif
-    if (skip) hipLaunchKernelGGL(k_conv8w<true>, dim3(tiles), dim3(512), 0, st, SGW_ARGS);
-    else hipLaunchKernelGGL(k_conv8w<false>, dim3(tiles), dim3(512), 0, st, SGW_ARGS);
+    static int ncu = 0;
+    if (!ncu) { hipDeviceProp_t pr; int dev = 0; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount; if (ncu <= 0) ncu = 256; }
+    const int grid = tiles < ncu ? tiles : ncu;
+    if (skip) hipLaunchKernelGGL(k_conv8x<true>, dim3(grid), dim3(512), 0, st, SGW_ARGS);
+    else hipLaunchKernelGGL(k_conv8x<false>, dim3(grid), dim3(512), 0, st, SGW_ARGS);
 #undef SGW_ARGS
     return 0;
 }
 
-}  // namespace sgo_conv8w
+}  // namespace sgo_conv8x
