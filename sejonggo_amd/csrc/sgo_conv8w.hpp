@@ -59,11 +59,7 @@ constexpr int LW0 = 0, LB0 = 40960, LB1 = 73728, LW1 = 106496, LZ = 147456, LZ_B
 #define SGW_LGKM0()                                    \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
     __builtin_amdgcn_sched_barrier(0)
-#ifdef SGW_NOPRIO
-#define SGW_PRIO(x) do { } while (0)
-#else
 #define SGW_PRIO(x) __builtin_amdgcn_s_setprio(x)
-#endif
 #define SGW_VMWAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
 template <bool HAS_SKIP>
@@ -196,18 +192,14 @@ __global__ __launch_bounds__(512) void k_conv8w(const char *__restrict__ xb, con
         else SGW_VMWAIT(6);                    \
     } while (0)
 
-#ifdef SGW_WPA   // window piece issued in phase A: younger than weights[t+1] are that piece and the 4 weight DMAs
-#define SGW_WP_A(S2, c, tp) do { if ((S2) && (c) < 3 && (tp) < 5) SGW_STAGE_W((c) + 1, tp); } while (0)
-#define SGW_WP_B(c, tp) SGW_WAIT_B(4 + (((c) < 3 && (tp) < 5) ? 1 : 0))
-#else           // in phase B behind the weights: younger are the previous K-tile's piece, the 4 weight DMAs and this piece
-#define SGW_WP_A(S2, c, tp) do { } while (0)
+// window piece of the next chunk, issued in phase B behind the weights: younger than weights[t+1] are then the previous
+// K-tile's piece, the 4 weight DMAs and this piece
 #define SGW_WP_B(c, tp)                                                                      \
     do {                                                                                     \
         const bool wp_ = (c) < 3 && (tp) < 5, wpprev_ = (c) < 3 && (tp) >= 1 && (tp) <= 5;   \
         if (wp_) SGW_STAGE_W((c) + 1, tp);                                                   \
         SGW_WAIT_B(4 + (wp_ ? 1 : 0) + (wpprev_ ? 1 : 0));                                   \
     } while (0)
-#endif
 // one K-tile t, weights in buffer BUF, two phases of 32 MFMAs.  S2: whether K-tile t+2 exists (its weights are staged in
 // phase B into this tile's buffer, whose reads were retired in phase A); LASTW: wait used instead when nothing is staged
 // (0 = drain, 63 = none); EXTRA(ph): additional DMA (skip rows behind the last K-tile)
@@ -218,7 +210,6 @@ __global__ __launch_bounds__(512) void k_conv8w(const char *__restrict__ xb, con
         SGW_READ_B(BUF, 1, whi);                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                   \
         SGW_READ_A(0, t);                                                                    \
-        SGW_WP_A(S2, cA_, tA_);                                                              \
         EXTRA(0);                                                                            \
         SGW_SYNC_IN();                                                                       \
         SGW_MFMA(0, 0, wlo);                                                                 \
