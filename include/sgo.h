@@ -81,6 +81,11 @@ int sgo_unpack_dev(int S, int n, const uint32_t *d_packed, int32_t *d_board17, v
 int sgo_advance_legal_dev(int S, int n, const uint32_t *d_in, const int32_t *d_in_idx, const int32_t *d_moves,
                           const int32_t *d_colors, uint32_t *d_out, const int32_t *d_out_idx, uint32_t *d_legal,
                           int32_t *d_status, void *stream);
+/* Kernel form behind the non-aliasing board_advance launches (sgo_advance_legal_dev with disjoint dense in / out, the
+ * engine's leaf step): 0 = history stream + one lane per position (two launches), 1 = the same two in one launch,
+ * 2 = one half-wavefront per position (row per lane; csrc/sgo_rows.hpp), -1 = by batch size (default: 2 up to 32 768
+ * positions, 1 up to 65 536, 0 above).  Returns the previous mode; other values only query.  All forms are bit-identical. */
+int sgo_advance_mode(int mode);
 int sgo_legal_dev(int S, int n, const uint32_t *d_packed, const int32_t *d_idx, uint32_t *d_legal, void *stream);
 /* d_result[i] = {winner, black, white_stones_and_territory (without komi)} as 3 x int32 */
 int sgo_score_dev(int S, int n, const uint32_t *d_packed, const int32_t *d_idx, double komi, int32_t *d_result,

@@ -193,10 +193,12 @@ __global__ __launch_bounds__(512) void k_conv8w(const char *__restrict__ xb, con
     } while (0)
 
 // window piece of the next chunk, issued in phase B behind the weights: younger than weights[t+1] are then the previous
-// K-tile's piece, the 4 weight DMAs and this piece
+// K-tile's piece, the 4 weight DMAs and this piece -- counted per WAVE: a wave whose rows of a piece lie beyond the window
+// (NROWS < 320) issues nothing for it, and a count that assumed it had would leave one weight DMA unretired
+#define SGW_WP_ISSUED(c, tp) ((c) < 3 && (tp) >= 0 && (tp) < 5 && ((tp) * 8 + wid) * 8 < NROWS)
 #define SGW_WP_B(c, tp)                                                                      \
     do {                                                                                     \
-        const bool wp_ = (c) < 3 && (tp) < 5, wpprev_ = (c) < 3 && (tp) >= 1 && (tp) <= 5;   \
+        const bool wp_ = SGW_WP_ISSUED(c, tp), wpprev_ = SGW_WP_ISSUED(c, (tp) - 1);         \
         if (wp_) SGW_STAGE_W((c) + 1, tp);                                                   \
         SGW_WAIT_B(4 + (wp_ ? 1 : 0) + (wpprev_ ? 1 : 0));                                   \
     } while (0)

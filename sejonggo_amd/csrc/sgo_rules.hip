@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "sgo_bits.hpp"
+#include "sgo_rows.hpp"
 #include "sgo_common.hpp"
 
 namespace sgo {
@@ -217,6 +218,32 @@ __global__ __launch_bounds__(64) void k_board_advance(int n, const int *n_dev, i
     if (status) status[i] = st ? st : mover;
 }
 
+// The row-per-lane form (sgo_rows.hpp): one 32-lane half per leaf, history move included.  For the engine's small
+// per-step launches: 8 192 leaves are 4 096 wavefronts here instead of 128, and a leaf's latency is a few hundred
+// instructions instead of a few thousand.
+template <int S>
+__global__ __launch_bounds__(64) void k_board_advance_rows(int n, const int *n_dev, const uint32_t *in, const int32_t *in_idx,
+                                                           const int32_t *moves, const int32_t *colors, uint32_t *out,
+                                                           const int32_t *out_idx, uint32_t *legal, const int32_t *legal_idx,
+                                                           int32_t *status) {
+    using G = Geo<S>;
+    if (n_dev) n = *n_dev;
+    const int half = threadIdx.x >> 5, y = threadIdx.x & 31;
+    const int i = blockIdx.x * 2 + half;
+    if (i >= n) return;
+    const uint32_t *src = in + (size_t)(in_idx ? in_idx[i] : i) * G::RW;
+    uint32_t *dst = out + (size_t)(out_idx ? out_idx[i] : i) * G::RW;
+    uint32_t *lg = legal ? legal + (size_t)(legal_idx ? legal_idx[i] : i) * G::NW : nullptr;
+    bool swap_first = false;
+    int mover = white_to_play<S>(src) ? -1 : 1;
+    if (colors) {
+        int c = colors[i];
+        if (c != 0 && c != mover) { swap_first = true; mover = -mover; }
+    }
+    const int st = rows::advance_record_rows<S>(src, dst, moves[i], swap_first, lg, half, y);
+    if (status && y == 0) status[i] = st ? st : mover;
+}
+
 template <int S>
 __global__ __launch_bounds__(256) void k_legal(int n, const uint32_t *packed, const int32_t *idx, uint32_t *legal) {
     using G = Geo<S>;
@@ -373,13 +400,21 @@ __global__ __launch_bounds__(256) void k_bias_act(long n8, int C8, const half8_t
 // Two launches on the caller's stream: the streaming history move, then the register kernel.  (Running the two
 // on separate streams was measured: they contend for the memory system at low stone density and the fork/join
 // events cost more than the overlap saves at the engine's 8 192-leaf launches.)
-static int adv_mode() {   // SGO_ADV_MODE: 0 two launches, 1 one heterogeneous launch, unset: by batch size
-    static int m = -2;
-    if (m == -2) {
+// SGO_ADV_MODE / sgo_advance_mode(): 0 two launches (history stream + lane-per-leaf), 1 one heterogeneous launch of the
+// same two, 2 row-per-lane (one half-wave per leaf), -1 (default): by batch size
+static constexpr int ROWS_MAX_LEAVES = 1 << 15;   // above this the lane-per-leaf form has the chip filled
+static int g_adv_mode = -2;
+static int adv_mode() {
+    if (g_adv_mode == -2) {
         const char *e = getenv("SGO_ADV_MODE");
-        m = e ? atoi(e) : -1;
+        g_adv_mode = e ? atoi(e) : -1;
     }
-    return m;
+    return g_adv_mode;
+}
+int set_advance_mode(int m) {
+    const int old = adv_mode();
+    if (m >= -1 && m <= 2) g_adv_mode = m;
+    return old;
 }
 
 int launch_advance_split(int S, int n_max, const int *d_n, const uint32_t *d_in, const int32_t *d_in_idx,
@@ -387,8 +422,13 @@ int launch_advance_split(int S, int n_max, const int *d_n, const uint32_t *d_in,
                          uint32_t *d_legal, const int32_t *d_legal_idx, int32_t *d_status, hipStream_t st) {
     if (n_max <= 0) return SGO_OK;
     int mode = adv_mode();
-    if (mode < 0) mode = (n_max <= (1 << 16)) ? 1 : 0;
+    if (mode < 0) mode = (n_max <= ROWS_MAX_LEAVES) ? 2 : (n_max <= (1 << 16)) ? 1 : 0;
     SGO_DISPATCH(S, {
+        if (mode == 2) {
+            k_board_advance_rows<kS><<<dim3(cdiv(n_max, 2)), dim3(64), 0, st>>>(n_max, d_n, d_in, d_in_idx, d_moves, d_colors, d_out,
+                                                                               d_out_idx, d_legal, d_legal_idx, d_status);
+        } else
+        {
         constexpr int CPR = (Geo<kS>::NW % 4 == 0) ? 14 * Geo<kS>::NW / 4 : 14 * Geo<kS>::NW;
         if (mode == 1) {
             const int nbc = cdiv(n_max, 64);
@@ -410,6 +450,7 @@ int launch_advance_split(int S, int n_max, const int *d_n, const uint32_t *d_in,
                 k_history_shift<kS, false><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(n_max, d_n, d_in, d_in_idx, d_colors, d_out, d_out_idx);
             k_advance_planes<kS><<<dim3(cdiv(n_max, 64)), dim3(64), 0, st>>>(n_max, d_n, d_in, d_in_idx, d_moves, d_colors, d_out,
                                                                              d_out_idx, d_legal, d_legal_idx, d_status);
+        }
         }
     });
     SGO_HIP(hipGetLastError());
@@ -479,6 +520,7 @@ extern "C" {
 
 const char *sgo_last_error(void) { return g_err.c_str(); }
 int sgo_version(void) { return 1; }
+int sgo_advance_mode(int mode) { return set_advance_mode(mode); }
 int sgo_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;

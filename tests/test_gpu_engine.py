@@ -475,6 +475,21 @@ def test_tower_conv_kernel(L):
             y3 = torch.full_like(y, 3.0)
             L.check(lib.sgo_conv3x3_tower_dev(n, h, wd, x.data_ptr(), w.data_ptr(), b.data_ptr(), sp, y3.data_ptr(), st))
             assert torch.equal(y, y3)
+    # race screen at a chip-filling size: a missing wait shows up as run-to-run differences (this is how the per-wave DMA
+    # count of the phase-B wait was caught)
+    n, h, wd = 4096, 17, 17
+    x = (torch.randn(n, h, wd, 256, device="cuda") * 0.5).half()
+    w = (torch.randn(256, 3, 3, 256, device="cuda") * 0.03).half()
+    b = torch.randn(256, device="cuda").half()
+    skip = torch.randn(n, h, wd, 256, device="cuda").half()
+    y = torch.empty_like(skip)
+    L.check(lib.sgo_conv3x3_tower_dev(n, h, wd, x.data_ptr(), w.data_ptr(), b.data_ptr(), skip.data_ptr(), y.data_ptr(), st))
+    y0 = y.clone()
+    for _ in range(25):
+        y.fill_(1.0)
+        L.check(lib.sgo_conv3x3_tower_dev(n, h, wd, x.data_ptr(), w.data_ptr(), b.data_ptr(), skip.data_ptr(), y.data_ptr(), st))
+        assert torch.equal(y, y0)
+    del x, skip, y, y0
     # exact integer data: every product and sum is representable, so the result must be exact (catches a wrong tap,
     # channel or swizzle that random data could hide inside the tolerance)
     n, h, wd = 4, 17, 17

@@ -246,3 +246,53 @@ def test_full_size_properties_19(L):
             assert torch.equal(inpl, nxt)
             cur, nxt = nxt, cur
         torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("S", [5, 7, 9, 13, 19])
+def test_advance_kernel_forms_agree(L, S):
+    """The three kernel forms behind board_advance (history stream + lane per position, the same in one launch, and one
+    half-wavefront per position = csrc/sgo_rows.hpp) give identical records, legal sets and statuses: long seeded playouts
+    (captures, suicides, ko shapes, passes, dense end-game boards), colour overrides, occupied and out-of-range moves."""
+    import torch
+    lib = L.load()
+    A, NW, RW = S * S + 1, lib.sgo_plane_words(S), lib.sgo_packed_words(S)
+    n = 2048 + 1                          # odd: the last wavefront of the row-per-lane form runs one half only
+    g = torch.Generator(device="cuda")
+    g.manual_seed(100 + S)
+    cur = torch.zeros((n, RW), dtype=torch.int32, device="cuda")
+    legal = torch.full((n, NW), -1, dtype=torch.int32, device="cuda")
+    legal[:, NW - 1] = (1 << ((A - 1) % 32 + 1)) - 1
+    shifts = torch.arange(32, device="cuda", dtype=torch.int32)
+    st = L.stream_ptr()
+    old = lib.sgo_advance_mode(-1)
+    try:
+        for ply in range(min(2 * S * S + 8, 330)):
+            bits = ((legal.unsqueeze(-1) >> shifts) & 1).reshape(n, NW * 32)[:, :A].float()
+            bits[:, A - 1] = 0.02
+            moves = torch.multinomial(bits, 1, generator=g).reshape(n).to(torch.int32)
+            # a few illegal-by-mask points (suicides / own eyes are executed by make_play), occupied points and bad indices
+            r = torch.rand(n, generator=g, device="cuda")
+            rnd = torch.randint(0, A - 1, (n,), generator=g, device="cuda", dtype=torch.int32)
+            moves = torch.where(r < 0.05, rnd, moves)
+            moves = torch.where(r > 0.995, torch.full_like(moves, A + 3), moves)
+            colors = torch.randint(-1, 2, (n,), generator=g, device="cuda", dtype=torch.int32)
+            colors = torch.where(torch.rand(n, generator=g, device="cuda") < 0.8, torch.zeros_like(colors), colors)
+            outs = []
+            for mode in (0, 1, 2):
+                lib.sgo_advance_mode(mode)
+                o = torch.zeros_like(cur)
+                lg = torch.zeros_like(legal)
+                stt = torch.zeros(n, dtype=torch.int32, device="cuda")
+                L.check(lib.sgo_advance_legal_dev(S, n, L.ptr(cur), None, L.ptr(moves), L.ptr(colors), L.ptr(o), None, L.ptr(lg), L.ptr(stt), st))
+                ok = (stt.abs() == 1)
+                outs.append((o * ok.unsqueeze(1), lg * ok.unsqueeze(1), stt))   # failed plies leave their outputs undefined
+            for k in (1, 2):
+                assert torch.equal(outs[0][2], outs[k][2]), (S, ply, k, "status")
+                assert torch.equal(outs[0][0], outs[k][0]), (S, ply, k, "record")
+                assert torch.equal(outs[0][1], outs[k][1]), (S, ply, k, "legal")
+            ok = (outs[2][2].abs() == 1).unsqueeze(1)
+            cur = torch.where(ok, outs[2][0], cur)
+            legal = torch.where(ok, outs[2][1], legal)
+        torch.cuda.synchronize()
+    finally:
+        lib.sgo_advance_mode(old)
