@@ -1,4 +1,4 @@
-// conv8p.hip -- experiment harness copy of the hand-written tower convolution (see sejonggo_amd/csrc/sgo_conv8p.hip
+// conv8p.hip -- experiment harness copy of the hand-written tower convolution (see sejonggo_amd/csrc/sgo_conv8w.hpp
 // for the product version and the design notes).  Build:
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared conv8p.hip -o libconv8p.so
 #include <hip/hip_runtime.h>
@@ -19,7 +19,7 @@ static inline int launch(int n, int h, int w, const void *x, const void *wgt, co
 #endif
 }
 #else
-#include "../../sejonggo_amd/csrc/sgo_conv8p.hpp"
+#include "conv8p_kernel.hpp"
 #endif
 
 extern "C" int conv8p_run(int n, int h, int w, const void *x, const void *wgt, const void *bias, const void *skip, void *y,
