@@ -5,8 +5,12 @@ Contract (one JSON line on rank 0): see the task statement.  A "step" = every re
 by ONE move: 1 root evaluation + sims/energy search rounds of `energy` leaves each, i.e. (1 + 400)
 network evaluations, 400 board_advance leaf positions and one move record per game.
   value     = n_gpus * games_per_gpu * steps / seconds   (whole job, positions/sec)
-  roofline  = the board_advance kernel (k_leaf_advance): algorithmic bytes per launch (1834 B per leaf at
-              19x19) / its average duration, HIP events on the launch stream inside sgo_step
+  roofline  = the step's dominant kernel (98 % of the GPU time): the hand-written tower convolution k_conv8w,
+              bound "mfma": FLOPs of its launches / their durations, every launch of the timed region bracketed by
+              HIP events on the launch stream (both batch sizes; "largest_batch" = the games x energy batches alone)
+  roofline_board_advance = the board_advance kernel in situ, bound "hbm": algorithmic bytes per launch (1834 B per
+              leaf at 19x19, SURVEY.md §8d) / its average duration, HIP events on the launch stream inside sgo_step;
+              roofline_saturated = the same kernel family on a chip-filling dense batch
   cpu_baseline = the oracle (C restatement of the reference's rules + tree) driving the same net on torch
               CPU fp32, on a bounded sample, host cores stated ("kind": "port")
 Multi-GPU: one process per GPU, games sharded statically, no collective in the search; the per-step move
@@ -167,39 +171,6 @@ def saturated_advance(S, n=1 << 18, ply=60, iters=10):
             "inputs": "seeded random legal playouts, ply %d" % ply}
 
 
-def tower_conv_roofline(n, side, channels=256, iters=10):
-    """The net's dominant kernel alone: the hand-written tower convolution (csrc/sgo_conv8w.hpp) at the bench's own
-    batch shape, with skip, timed with HIP events on the launch stream.  Inputs are a ReLU'd random activation (what the
-    tower sees) and weights of the scale the folded BatchNorm produces."""
-    import torch
-    from sejonggo_amd import _lib as L
-    lib = L.require_gpu()
-    if channels != 256 or side > 19:
-        return None
-    torch.manual_seed(7)
-    x = torch.relu(torch.randn(n, side, side, 256, device="cuda") * 0.5).half()
-    w = (torch.randn(256, 3, 3, 256, device="cuda") * 0.03).half()
-    b = torch.randn(256, device="cuda").half()
-    s = torch.relu(torch.randn(n, side, side, 256, device="cuda")).half()
-    y = torch.empty_like(s)
-    st = L.stream_ptr()
-    for _ in range(3):
-        L.check(lib.sgo_conv3x3_tower_dev(n, side, side, L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(s), L.ptr(y), st))
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        L.check(lib.sgo_conv3x3_tower_dev(n, side, side, L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(s), L.ptr(y), st))
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / iters
-    fl = 2.0 * n * side * side * 9 * 256 * 256
-    ach = fl / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "k_conv8w<skip> (tower 3x3 convolution 256->256 + bias + skip + ReLU, fp16 in / fp32 accumulate)",
-            "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": None,
-            "flops_per_launch": fl, "avg_launch_ms": ms, "launches": iters,
-            "shape": "n=%d, %dx%d, 256->256" % (n, side, side)}
-
-
 def main():
     args = parse()
     import numpy as np
@@ -266,6 +237,9 @@ def main():
     for _ in range(args.warmup):
         one_step()
     eng.advance_timing()
+    time_convs = args.net == "resnet" and not args.plain_net and hasattr(net, "conv_events")
+    if time_convs:
+        net.conv_events = []
     evals0 = eng.status.total_evals
     sync()
     t0 = time.perf_counter()
@@ -279,6 +253,15 @@ def main():
     dt = float(tmax.item())
     adv_ms, adv_n, adv_pos = eng.advance_timing()
     evals = eng.status.total_evals - evals0
+    conv_ms, conv_fl, conv_n, conv_big_ms, conv_big_n, conv_big_fl = 0.0, 0.0, 0, 0.0, 0, 0.0
+    if time_convs:
+        evs, net.conv_events = net.conv_events, None
+        big = max((f for _, _, f in evs), default=0.0)
+        for e0, e1, f in evs:
+            ms = e0.elapsed_time(e1)
+            conv_ms += ms; conv_fl += f; conv_n += 1
+            if f == big:
+                conv_big_ms += ms; conv_big_n += 1; conv_big_fl = f
     out = None
     if rank == 0:
         positions = world * G * args.steps
@@ -300,7 +283,7 @@ def main():
                                       if args.net == "resnet" else args.net + " stub net", args.symmetry),
                        "games_per_gpu": G, "sims": sims, "energy": E, "net_evals_per_position": (sims // E) * E + 1,
                        "sharding": "games g -> rank g mod N; RCCL gather of per-step records to rank 0"},
-            "roofline": {"bound": "hbm", "kernel": "k_board_advance (make_play + legal set of the new position; one launch: register blocks + history-stream blocks)",
+            "roofline_board_advance": {"bound": "hbm", "kernel": "board_advance in situ (make_play + legal set + history move of the step's leaf list; k_board_advance_rows up to 32 768 leaves, k_board_advance above)",
                          "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": None, "algorithmic_bytes_per_position": ALGO_BYTES.get(S, 0),
                          "positions_per_launch": per_launch, "avg_launch_ms": avg_ms, "launches": adv_n},
@@ -308,11 +291,24 @@ def main():
                     "achieved_tflops": (evals * sym_mult * flops / dt / 1e12) if flops else None,
                     "peak_tflops": 2500.0, "bound": "mfma"},
         }
+        if conv_n:
+            # the dominant kernel of the step (98 % of the GPU time): the tower convolution, timed launch by launch with HIP
+            # events on the launch stream inside the timed region; `achieved` is over ALL its launches (both batch sizes)
+            ach = conv_fl / (conv_ms * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": "sgo_conv8w::k_conv8w (tower 3x3 convolution 256->256 + bias (+ skip) + ReLU, fp16 in / fp32 accumulate; csrc/sgo_conv8w.hpp)",
+                               "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": None,
+                               "launches": conv_n, "avg_launch_ms": conv_ms / conv_n, "flops_per_launch_mean": conv_fl / conv_n,
+                               "largest_batch": {"launches": conv_big_n, "avg_launch_ms": conv_big_ms / max(conv_big_n, 1),
+                                                 "flops_per_launch": conv_big_fl,
+                                                 "achieved": conv_big_fl * conv_big_n / max(conv_big_ms * 1e-3, 1e-12) / 1e12},
+                               "share_of_step_time": conv_ms * 1e-3 / dt}
+        else:
+            out["roofline"] = dict(out["roofline_board_advance"])
         tr = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if os.path.isfile(tr) and (S, G, E) == (19, 1024, 8):
             try:
-                out["roofline"]["traffic"] = json.load(open(tr)).get("traffic_bytes_per_launch_corrected")
-                out["roofline"]["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
+                out["roofline_board_advance"]["traffic"] = json.load(open(tr)).get("traffic_bytes_per_launch_corrected")
+                out["roofline_board_advance"]["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
             except Exception:
                 pass
         if args.saturated and world == 1:
@@ -321,13 +317,6 @@ def main():
                 out["roofline_saturated"] = saturated_advance(S)
             except Exception as ex:
                 out["roofline_saturated"] = {"error": repr(ex)}
-            if args.net == "resnet" and not args.plain_net:
-                try:
-                    rm = tower_conv_roofline(G * E, S - 2, args.channels)
-                    if rm:
-                        out["roofline_mfma"] = rm
-                except Exception as ex:
-                    out["roofline_mfma"] = {"error": repr(ex)}
         if args.cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(args, S, sims, E, args.blocks, args.channels, args.symmetry)

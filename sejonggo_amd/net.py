@@ -172,6 +172,7 @@ class FusedInferenceNet(object):
         self.fused_conv = True     # conv + bias + skip + ReLU in one MFMA kernel (sgo_conv.hip); False: MIOpen + k_bias_act
         self.split_min = 1024
         self._side = None
+        self.conv_events = None    # list of (start, end, flops) HIP-event brackets around tower convolutions while set (bench.py)
 
     def flops_per_eval(self):
         return self._flops
@@ -191,9 +192,16 @@ class FusedInferenceNet(object):
         k = w.shape[0]
         y = torch.empty((n, k, h + 2 * pad - 2, wd + 2 * pad - 2), dtype=x.dtype, device=x.device,
                         memory_format=torch.channels_last)
+        timed = self.conv_events is not None and c == k == 256 and pad == 1
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         self._lib.check(self.lib.sgo_conv3x3_bias_act_dev(n, h, wd, c, k, pad, x.data_ptr(), w.data_ptr(), b.data_ptr(),
                                                           None if skip is None else skip.data_ptr(), y.data_ptr(),
                                                           torch.cuda.current_stream().cuda_stream), "sgo_conv3x3_bias_act_dev")
+        if timed:
+            e1.record()
+            self.conv_events.append((e0, e1, 2.0 * n * y.shape[2] * y.shape[3] * 9 * c * k))
         return y
 
     def _forward(self, X):
