@@ -72,6 +72,7 @@ __global__ __launch_bounds__(512) void k_conv8w(const char *__restrict__ xb, con
                                                  ) {
 #ifdef SGO_CONV8_STAMPS
     const long long st0 = __builtin_amdgcn_s_memtime();
+    const long long rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
     __shared__ __attribute__((aligned(1024))) char smem[LDS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -385,7 +386,7 @@ __global__ __launch_bounds__(512) void k_conv8w(const char *__restrict__ xb, con
     if (lane == 0) {
         long long *o = stamps + ((size_t)tile * 8 + wid) * 6;
         o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3; o[4] = __builtin_amdgcn_s_memrealtime();
-        o[5] = 0;
+        o[5] = rt0;
     }
 #endif
 }

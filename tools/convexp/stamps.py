@@ -26,6 +26,6 @@ for name, v in (("prologue", pro), ("main loop", main), ("epilogue", epi), ("tot
     print("%-10s cycles: median %8.0f  p10 %8.0f  p90 %8.0f   (wave 0: %8.0f, wave 7: %8.0f)" % (
         name, np.median(v), np.percentile(v, 10), np.percentile(v, 90), np.median(v[:, 0]), np.median(v[:, 7])))
 print("ideal main loop at 16 cyc/MFMA, 2 waves/SIMD: %d cycles" % (36 * 64 * 16 * 2))
-span = a[:, :, 3].max() - a[:, :, 0].min()
-rt = a[:, :, 4].max() - a[:, :, 4].min()
-print("kernel span %.0f cycles; realtime span %.0f ticks (100 MHz) -> clock %.3f GHz (lower bound, end stamps only)" % (span, rt, 0))
+clk = (a[:, :, 3] - a[:, :, 0]) / np.maximum(a[:, :, 4] - a[:, :, 5], 1) * 100.0   # s_memtime cycles per 100 MHz realtime tick
+print("in-kernel clock (delta s_memtime / delta s_memrealtime x 100 MHz): median %.0f MHz, p10 %.0f, p90 %.0f" % (
+    np.median(clk), np.percentile(clk, 10), np.percentile(clk, 90)))
