@@ -356,3 +356,17 @@ def smoke_selfplay():
     games = eng.run()
     assert len(games) == 8 and all(len(gd['moves']) == 3 for gd in games)
     eng.close()
+    # the production net form: FusedInferenceNet on the hand-written tower convolution, against its own fp32 torch module
+    from .net import build_fused_net
+    fnet, ref = build_fused_net(S, 2, 256, name="smoke256", seed=1, device="cuda")
+    x = torch.zeros((24, S, S, 17), dtype=torch.float16, device="cuda")
+    x[..., :16] = (torch.rand((24, S, S, 16), device="cuda") < 0.2).half()
+    x[..., 16] = 1.0
+    p1, v1 = fnet.predict_on_batch(x)
+    p0, v0 = ref.float().cuda().predict_on_batch(x.float())
+    assert float((p1 - p0).abs().max()) <= 2e-3 and float((v1 - v0).abs().max()) <= 5e-3, "fused net vs fp32 module"
+    eng = SelfPlayEngine(fnet, size=S, n_games=8, sims=16, energy=8, stop_exploration=2, num_moves=3, symmetry="random1")
+    eng.start_games(np.arange(8))
+    games = eng.run()
+    assert len(games) == 8 and all(len(gd['moves']) == 3 for gd in games)
+    eng.close()
