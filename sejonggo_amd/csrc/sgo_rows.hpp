@@ -66,16 +66,19 @@ struct Board {
         const uint32_t np = nbr4(pb);
         own |= pb;
         uint32_t emp = ~(own | opp) & M;
-        // opponent groups next to the stone that are left without an empty neighbour
-        {
+        // opponent groups next to the stone that are left without an empty neighbour (skipped by the whole wave when neither
+        // of its two positions has an opponent stone next to the new one: nothing could be captured)
+        if (__any((np & opp) != 0)) {
             const uint32_t alive = flood(opp & nbr4(emp), opp);
             const uint32_t dead = opp & ~alive;
             const uint32_t cap = flood(dead & np, dead);
             opp &= ~cap;
             emp |= cap;
         }
-        // the stone's own group: removed when it has no liberty left (suicide is executed, play.py:200-215)
-        {
+        // the stone's own group: removed when it has no liberty left (suicide is executed, play.py:200-215); a stone with an
+        // empty neighbour is alive, so the wave skips the fill when that holds for both of its positions
+        const bool no_lib = half_any(pb, half) && !half_any(np & emp, half);   // the same in every lane of the half
+        if (__any(no_lib)) {
             const uint32_t alive = flood(own & nbr4(emp), own);
             const bool hit = half_any(alive & pb, half);
             const uint32_t dead = own & ~alive;
