@@ -24,6 +24,11 @@
 //   A wave retires its own LDS reads before the barrier that ends its read interval, so a region may be re-staged from
 //   the next interval on; staged data is read one phase after the counted wait that retires it (weights[t+1] are waited
 //   for in phase B of K-tile t with exactly the younger DMAs left in flight: never vmcnt(0) in the loop).
+// * The K loop is unrolled over the nine taps (loop body = 18 K-tiles: taps x chunk parity): every tap shift, mask bit,
+//   buffer and weight offset is an immediate, and the per-phase address arithmetic is re-derived from opaque copies so
+//   that hipcc neither hoists 144 loop-invariant lane masks into SGPR pairs nor keeps 36 phases of addresses live.  The
+//   chip is power-limited under this kernel (tools/convexp/datadep.py): fewer vector / scalar instructions per MFMA is what
+//   this buys (+1.6 % over the runtime-decoded loop), not a shorter critical path.
 // * MFMA: v_mfma_f32_16x16x32_f16 with the WEIGHTS as the row operand, so a lane ends up with 4 consecutive output
 //   channels of one pixel.
 // * Epilogue through LDS: the skip rows arrive by DMA (lo half behind the last K-tile, hi half behind the lo half's
@@ -78,6 +83,7 @@ __global__ __launch_bounds__(512) void k_conv8w(const char *__restrict__ xb, con
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 2, wc = wid & 3;
+    const int swid = wid;
     const int tile = blockIdx.x;
     const int HW = H * W, HALO = W + 1, NROWS = 256 + 2 * HALO;
 
@@ -112,45 +118,54 @@ __global__ __launch_bounds__(512) void k_conv8w(const char *__restrict__ xb, con
 #define SGW_GLDS(src, ldsoff) \
     __builtin_amdgcn_global_load_lds((const SGW_AS1 void *)(src), (SGW_AS3 void *)((SGW_AS3 char *)smem + (ldsoff)), 16, 0, 0)
 
-// stage the channel granule G (0 lo, 1 hi) of K-tile ts into weight buffer BUF
-#define SGW_STAGE_B(BUF, G, ts)                                                                       \
+// stage the channel granule G (0 lo, 1 hi) of the K-tile whose weights start at byte koff_ of a filter row into buffer BUF
+#define SGW_STAGE_BK(BUF, G, koff_)                                                                   \
     do {                                                                                              \
-        const int kc_ = ((ts) * 57) >> 9, koff_ = ((ts) - 9 * kc_) * (CIN * 2) + kc_ * 128;           \
         int bo_ = boff00;                                                                             \
         asm volatile("" : "+v"(bo_));                                                                 \
         _Pragma("unroll") for (int i_ = 0; i_ < 2; i_++) {                                            \
-            const char *src_ = wb + (unsigned)((bo_ ^ (i_ * 64)) + (i_ * 8 + (G) * 128) * WROWB + koff_); \
-            SGW_GLDS_LOOP(src_, ((BUF) ? LB1 : LB0) + (G) * 16384 + (wid * 2 + i_) * 1024);                \
+            const char *src_ = wb + (unsigned)((bo_ ^ (i_ * 64)) + (i_ * 8 + (G) * 128) * WROWB + (koff_)); \
+            SGW_GLDS_LOOP(src_, ((BUF) ? LB1 : LB0) + (G) * 16384 + (swid * 2 + i_) * 1024);           \
         }                                                                                             \
     } while (0)
-// stage window piece `pc` (0..4) of channel chunk cc into window buffer (cc & 1): wave wid fills rows (pc*8+wid)*8 ..+7
-#define SGW_STAGE_W(cc, pc)                                                                           \
+#define SGW_STAGE_B(BUF, G, ts)                                                                       \
     do {                                                                                              \
-        const int id_ = (pc) * 8 + wid;                                                               \
+        const int kc_ = ((ts) * 57) >> 9;                                                             \
+        SGW_STAGE_BK(BUF, G, ((ts) - 9 * kc_) * (CIN * 2) + kc_ * 128);                               \
+    } while (0)
+// stage window piece `pc` (0..4) of the channel chunk at byte offset ccoff_ of a pixel row into window buffer WPAR: wave
+// wid fills rows (pc*8+wid)*8 ..+7
+#define SGW_STAGE_WK(WPAR, ccoff_, pc)                                                                \
+    do {                                                                                              \
+        const int id_ = (pc) * 8 + swid;                                                               \
         if (id_ * 8 < NROWS) {                                                                        \
             int la_ = lane;                                                                           \
             asm volatile("" : "+v"(la_));                                                             \
             int q_ = tile * 256 - HALO + id_ * 8 + (la_ >> 3);                                        \
             q_ = q_ < 0 ? 0 : (q_ < M ? q_ : M - 1);                                                  \
-            const char *src_ = xb + (unsigned)(q_ * ROWB + (cc) * 128 + wsrc);                        \
-            SGW_GLDS_LOOP(src_, (((cc) & 1) ? LW1 : LW0) + id_ * 1024);                                    \
+            const char *src_ = xb + (unsigned)(q_ * ROWB + (ccoff_) + wsrc);                          \
+            SGW_GLDS_LOOP(src_, ((WPAR) ? LW1 : LW0) + id_ * 1024);                                   \
         }                                                                                             \
     } while (0)
+#define SGW_STAGE_W(cc, pc) SGW_STAGE_WK((cc) & 1, (cc) * 128, pc)
 #define SGW_LDS16(off) (*reinterpret_cast<const half8 *>(smem + (off)))
-// pixel fragments of half G for K-tile t: window row = rowA + G*128 + mt*16 + shift(tap), zero row where the tap is off
-// the board
-#define SGW_READ_A(G, t)                                                                              \
+// pixel fragments of half G for tap T (compile time) from window buffer WPAR: window row = rowA + G*128 + mt*16 + shift(T),
+// zeros where the tap is off the board
+#define SGW_SHIFT(T) (((T) / 3 == 0 ? -W : (T) / 3 == 2 ? W : 0) + (T) % 3 - 1)
+#define SGW_READ_A(G, T, WPAR)                                                                        \
     do {                                                                                              \
-        const int cc_ = ((t) * 57) >> 9, tap_ = (t) - 9 * cc_;                                        \
-        const int dy_ = (tap_ * 11) >> 5, dx_ = tap_ - 3 * dy_;                                       \
-        const int rl_ = rowA + (dy_ - 1) * W + (dx_ - 1);                                             \
+        int ra_ = rowA;                                                                               \
+        asm volatile("" : "+v"(ra_));   /* opaque: keeps 36 phases of address arithmetic from being hoisted / kept live */ \
+        const int rl_ = ra_ + SGW_SHIFT(T);                                                           \
         const int c0_ = (((lane >> 4) ^ rl_) & 7) << 4;                                               \
-        const int b0_ = ((cc_ & 1) ? LW1 : LW0) + (G) * 16384 + (rl_ << 7) + c0_, b1_ = b0_ ^ 64;     \
+        const int b0_ = ((WPAR) ? LW1 : LW0) + (G) * 16384 + (rl_ << 7) + c0_, b1_ = b0_ ^ 64;        \
         /* an off-board tap reads zeros from the SAME bank slot its window address has (row parity, chunk): no new */ \
         /* bank conflict with the lanes that do read the window */                                    \
         const int z0_ = LZ + ((rl_ & 1) << 7) + c0_, z1_ = z0_ ^ 64;                                  \
+        int mka_ = mk[G][0], mkb_ = mk[G][1];                                                         \
+        asm volatile("" : "+v"(mka_), "+v"(mkb_));   /* opaque: 144 loop-invariant lane masks would live in SGPR pairs */ \
         _Pragma("unroll") for (int mt_ = 0; mt_ < 4; mt_++) {                                         \
-            const bool ok_ = (mk[G][mt_ >> 1] >> ((mt_ & 1) * 9 + tap_)) & 1;                         \
+            const bool ok_ = (((mt_ >> 1) ? mkb_ : mka_) & (1 << ((mt_ & 1) * 9 + (T)))) != 0;        \
             pa[mt_][0] = SGW_LDS16((ok_ ? b0_ : z0_) + mt_ * 2048);                                   \
             pa[mt_][1] = SGW_LDS16((ok_ ? b1_ : z1_) + mt_ * 2048);                                   \
         }                                                                                             \
@@ -193,44 +208,46 @@ __global__ __launch_bounds__(512) void k_conv8w(const char *__restrict__ xb, con
         else SGW_VMWAIT(6);                    \
     } while (0)
 
-// window piece of the next chunk, issued in phase B behind the weights: younger than weights[t+1] are then the previous
-// K-tile's piece, the 4 weight DMAs and this piece -- counted per WAVE: a wave whose rows of a piece lie beyond the window
-// (NROWS < 320) issues nothing for it, and a count that assumed it had would leave one weight DMA unretired
-#define SGW_WP_ISSUED(c, tp) ((c) < 3 && (tp) >= 0 && (tp) < 5 && ((tp) * 8 + wid) * 8 < NROWS)
-#define SGW_WP_B(c, tp)                                                                      \
-    do {                                                                                     \
-        const bool wp_ = SGW_WP_ISSUED(c, tp), wpprev_ = SGW_WP_ISSUED(c, (tp) - 1);         \
-        if (wp_) SGW_STAGE_W((c) + 1, tp);                                                   \
-        SGW_WAIT_B(4 + (wp_ ? 1 : 0) + (wpprev_ ? 1 : 0));                                   \
-    } while (0)
-// one K-tile t, weights in buffer BUF, two phases of 32 MFMAs.  S2: whether K-tile t+2 exists (its weights are staged in
-// phase B into this tile's buffer, whose reads were retired in phase A); LASTW: wait used instead when nothing is staged
-// (0 = drain, 63 = none); EXTRA(ph): additional DMA (skip rows behind the last K-tile)
-#define SGW_TILE(BUF, t, S2, LASTW, EXTRA)                                                   \
-    do {                                                                                     \
-        const int cA_ = ((t) * 57) >> 9, tA_ = (t) - 9 * cA_;                                \
-        SGW_READ_B(BUF, 0, wlo);                                                             \
-        SGW_READ_B(BUF, 1, whi);                                                             \
-        __builtin_amdgcn_sched_barrier(0);                                                   \
-        SGW_READ_A(0, t);                                                                    \
-        EXTRA(0);                                                                            \
-        SGW_SYNC_IN();                                                                       \
-        SGW_MFMA(0, 0, wlo);                                                                 \
-        SGW_MFMA(0, 1, whi);                                                                 \
-        SGW_SYNC_OUT();                                                                      \
-        SGW_READ_A(1, t);                                                                    \
-        if (S2) {                                                                            \
-            SGW_STAGE_B(BUF, 0, (t) + 2);                                                    \
-            SGW_STAGE_B(BUF, 1, (t) + 2);                                                    \
-            SGW_WP_B(cA_, tA_);                                                              \
-        } else {                                                                             \
-            EXTRA(1);                                                                        \
-            SGW_VMWAIT(LASTW);                                                               \
-        }                                                                                    \
-        SGW_SYNC_IN();                                                                       \
-        SGW_MFMA(1, 1, whi);                                                                 \
-        SGW_MFMA(1, 0, wlo);                                                                 \
-        SGW_SYNC_OUT();                                                                      \
+// One K-tile with everything but the chunk pair index kk (0 / 1) known at compile time: tap T, chunk parity CP (chunk cc =
+// 2 kk + CP), weight buffer BUF = (T + CP) & 1.  Tile index t = 18 kk + 9 CP + T.  Two phases of 32 MFMAs:
+//   phase A: read chan-lo, chan-hi, pixel-lo                                                | MFMA (lo,lo) (lo,hi)
+//   phase B: read pixel-hi | stage weights[t+2], window piece of chunk cc+1 (taps 0..4)     | MFMA (hi,hi) (hi,lo)
+// The counted wait of phase B retires weights[t+1] (4 DMAs issued one K-tile ago); younger than those are the previous
+// K-tile's window piece, the 4 weight DMAs and this tile's piece -- counted per WAVE (a wave whose rows of piece 4 lie
+// beyond the window issues nothing for it).
+#define SGW_WP_COND(CP, TP) ((TP) >= 0 && (TP) < 5 && ((CP) == 0 || kk == 0) && ((TP) < 4 || (4 * 8 + swid) * 8 < NROWS))
+#define SGW_TILE_U(T, CP)                                                                                 \
+    do {                                                                                                  \
+        constexpr int BUF_ = ((T) + (CP)) & 1, T2_ = ((T) + 2) % 9, CARRY_ = ((T) + 2) / 9;               \
+        int swid = wid;                                                                                   \
+        asm volatile("" : "+s"(swid));   /* opaque per K-tile: LDS-DMA offsets are recomputed, not kept in 100+ SGPRs */ \
+        const bool last2_ = (CP) == 1 && (T) >= 7 && kk == 1;   /* K-tiles 34 and 35: nothing left to stage */ \
+        SGW_READ_B(BUF_, 0, wlo);                                                                         \
+        SGW_READ_B(BUF_, 1, whi);                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+        SGW_READ_A(0, T, CP);                                                                             \
+        if (HAS_SKIP && (CP) == 1 && (T) == 8 && kk == 1) SGW_SKIP_LO(0);                                 \
+        SGW_SYNC_IN();                                                                                    \
+        SGW_MFMA(0, 0, wlo);                                                                              \
+        SGW_MFMA(0, 1, whi);                                                                              \
+        SGW_SYNC_OUT();                                                                                   \
+        SGW_READ_A(1, T, CP);                                                                             \
+        if (!last2_) {                                                                                    \
+            const int koff_ = T2_ * (CIN * 2) + ((CP) + CARRY_) * 128 + kk * 256;                         \
+            SGW_STAGE_BK(BUF_, 0, koff_);                                                                 \
+            SGW_STAGE_BK(BUF_, 1, koff_);                                                                 \
+            const bool wp_ = SGW_WP_COND(CP, T), wpprev_ = SGW_WP_COND(CP, (T) - 1);                      \
+            if (wp_) SGW_STAGE_WK(((CP) + 1) & 1, (2 * kk + (CP) + 1) * 128, T);                          \
+            SGW_WAIT_B(4 + (wp_ ? 1 : 0) + (wpprev_ ? 1 : 0));                                            \
+        } else if ((T) == 7) {                                                                            \
+            SGW_VMWAIT(0);   /* K-tile 34: K-tile 35's weights */                                         \
+        } else {                                                                                          \
+            if (HAS_SKIP) SGW_SKIP_LO(1);                                                                 \
+        }                                                                                                 \
+        SGW_SYNC_IN();                                                                                    \
+        SGW_MFMA(1, 1, whi);                                                                              \
+        SGW_MFMA(1, 0, wlo);                                                                              \
+        SGW_SYNC_OUT();                                                                                   \
     } while (0)
 
     // ---- prologue: window of chunk 0, K-tile 0's weights; K-tile 1's weights stay in flight
@@ -282,17 +299,15 @@ __global__ __launch_bounds__(512) void k_conv8w(const char *__restrict__ xb, con
 #define SGW_SKIP_LO(ph) \
     do { SGW_STAGE_SKIP(0, 4 * (ph)); SGW_STAGE_SKIP(0, 4 * (ph) + 1); SGW_STAGE_SKIP(0, 4 * (ph) + 2); SGW_STAGE_SKIP(0, 4 * (ph) + 3); } while (0)
 
-    for (int t = 0; t < NTILE - 2; t += 2) {
-        SGW_TILE(0, t, true, 0, SGW_NOEXTRA);
-        SGW_TILE(1, t + 1, true, 0, SGW_NOEXTRA);
+    int elane = lane;   // opaque copy (made so inside the loop's last iteration): keeps the epilogue's address arithmetic late
+    for (int kk = 0; kk < 2; kk++) {
+        if (kk == 1) asm volatile("" : "+v"(elane));
+        SGW_TILE_U(0, 0); SGW_TILE_U(1, 0); SGW_TILE_U(2, 0); SGW_TILE_U(3, 0); SGW_TILE_U(4, 0);
+        SGW_TILE_U(5, 0); SGW_TILE_U(6, 0); SGW_TILE_U(7, 0); SGW_TILE_U(8, 0);
+        SGW_TILE_U(0, 1); SGW_TILE_U(1, 1); SGW_TILE_U(2, 1); SGW_TILE_U(3, 1); SGW_TILE_U(4, 1);
+        SGW_TILE_U(5, 1); SGW_TILE_U(6, 1); SGW_TILE_U(7, 1); SGW_TILE_U(8, 1);
     }
-    SGW_TILE(0, NTILE - 2, false, 0, SGW_NOEXTRA);   // drain: K-tile 35's weights
-    int elane = lane;   // opaque copy: keeps the epilogue's address arithmetic from being hoisted above the main loop
     asm volatile("" : "+v"(elane));
-    // the last K-tile has nothing to stage: its DMA slots carry the lo half of the skip tile into [0, 64 KiB) (window
-    // buffer 0 and weight buffer 0, idle since K-tile 34)
-    if constexpr (HAS_SKIP) SGW_TILE(1, NTILE - 1, false, 63, SGW_SKIP_LO);
-    else SGW_TILE(1, NTILE - 1, false, 63, SGW_NOEXTRA);
     if (wr == 0) __builtin_amdgcn_s_barrier();
 #ifdef SGO_CONV8_STAMPS
     const long long st2 = __builtin_amdgcn_s_memtime();

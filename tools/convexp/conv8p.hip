@@ -5,14 +5,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
-#ifdef USE_CONV8U
-#include "conv8u.hpp"
-namespace sgo_conv8w = sgo_conv8u;
-#define USE_CONV8W 1
-#elif defined(USE_CONV8W)
-#include "../../sejonggo_amd/csrc/sgo_conv8w.hpp"
-#endif
 #ifdef USE_CONV8W
+#include "../../sejonggo_amd/csrc/sgo_conv8w.hpp"
 namespace sgo_conv8p {
 #ifdef SGO_CONV8_STAMPS
 static inline int launch(int n, int h, int w, const void *x, const void *wgt, const void *bias, const void *skip, void *y, const void *, hipStream_t st, long long *stamps) {
