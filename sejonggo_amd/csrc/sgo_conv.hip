@@ -80,6 +80,10 @@ extern "C" int sgo_conv3x3_tower_dev(int n, int h, int w, const void *d_x, const
         set_error("sgo_conv3x3_tower_dev: bad argument (256 -> 256 channels, pad 1, board width <= 19)");
         return SGO_ERR_ARG;
     }
+    if ((((uintptr_t)d_x | (uintptr_t)d_w | (uintptr_t)d_y | (uintptr_t)d_skip) & 15) || ((uintptr_t)d_bias & 7)) {
+        set_error("sgo_conv3x3_tower_dev: x, w, skip, y must be 16-byte aligned (bias 8-byte): the kernel moves 16 B per lane");
+        return SGO_ERR_ARG;
+    }
     // the kernel addresses pixels with 32-bit byte offsets: batches beyond 2^31 bytes per tensor run in slices
     const long per = (long)h * w * sgo_conv8w::ROWB;
     long max_n = ((1L << 31) - 1) / per;

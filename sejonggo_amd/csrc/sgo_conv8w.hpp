@@ -430,3 +430,31 @@ static inline int launch(int n, int h, int w, const void *x, const void *wgt, co
 }
 
 }  // namespace sgo_conv8w
+
+// the kernel's working macros stay private to this header
+#undef SGW_ARGS
+#undef SGW_DS_READ128
+#undef SGW_DS_READ64
+#undef SGW_DS_WRITE64
+#undef SGW_GLDS
+#undef SGW_GLDS_LOOP
+#undef SGW_LDS16
+#undef SGW_LGKM0
+#undef SGW_MFMA
+#undef SGW_NOEXTRA
+#undef SGW_PRIO
+#undef SGW_READ_A
+#undef SGW_READ_B
+#undef SGW_SHIFT
+#undef SGW_SKIP_LO
+#undef SGW_STAGE_B
+#undef SGW_STAGE_BK
+#undef SGW_STAGE_SKIP
+#undef SGW_STAGE_W
+#undef SGW_STAGE_WK
+#undef SGW_SYNC_IN
+#undef SGW_SYNC_OUT
+#undef SGW_TILE_U
+#undef SGW_VMWAIT
+#undef SGW_WAIT_B
+#undef SGW_WP_COND
