@@ -1,6 +1,7 @@
 """Model loading with the reference's names (model.py:125-163 load_best_model / load_latest_model).
 
-The reference loads Keras .h5 files; importing those weights is SURVEY.md §8f row 2 ("next").  Here a
+The reference loads Keras .h5 files; `keras_import.load_keras_h5` assigns one to a PolicyValueNet where h5py exists
+(the array mapping is tested, the container reader needs h5py).  Here a
 model is a PolicyValueNet (net.py) restored from `<MODEL_DIR>/<name>.pt` (a torch state_dict saved by
 `save_model`) when present, otherwise random-init with the reference's initial name `model_0`."""
 import os

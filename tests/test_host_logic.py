@@ -175,3 +175,43 @@ def test_hdf5_min_checksum_and_round_trip(tmp_path):
     with h5py.File(path, "r") as f:
         for k in want:
             assert np.array_equal(f[k][()], want[k])
+
+
+def test_keras_layer_mapping_round_trip():
+    """keras_import: a PolicyValueNet exported to Keras-layout arrays (model.py:55-95 layer order and names) and read back
+    from a shuffled layer list is the same network bit for bit; wrong depth and wrong shapes are errors.  (The HDF5 container
+    itself needs h5py: parity unpinned, no Keras file ships with the reference.)"""
+    import random
+    import numpy as np
+    import pytest
+    import torch
+    from sejonggo_amd.keras_import import assign_keras_layers, export_keras_layers
+    from sejonggo_amd.net import PolicyValueNet
+    torch.manual_seed(3)
+    a = PolicyValueNet(9, n_blocks=5, channels=16, name="a").eval()
+    for m in a.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.2)
+            m.running_var.uniform_(0.5, 2.0)
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.1)
+    layers = export_keras_layers(a, first_index=7)          # conv2d_7 .. conv2d_19: numeric, not lexicographic, order
+    assert layers[0][1][0].shape == (3, 3, 17, 16) and layers[-1][1][0].shape == (256, 1)
+    layers += [("activation_3", []), ("add_1", [])]
+    random.Random(0).shuffle(layers)
+    b = PolicyValueNet(9, n_blocks=5, channels=16, name="b").eval()
+    assign_keras_layers(b, layers)
+    sa, sb = a.state_dict(), b.state_dict()
+    for k in sa:
+        if not k.endswith("num_batches_tracked"):
+            assert torch.equal(sa[k], sb[k]), k
+    x = (torch.rand(3, 9, 9, 17) < 0.2).float()
+    pa, va = a.predict_on_batch(x)
+    pb, vb = b.predict_on_batch(x)
+    assert torch.equal(pa, pb) and torch.equal(va, vb)
+    with pytest.raises(ValueError):
+        assign_keras_layers(PolicyValueNet(9, n_blocks=4, channels=16), layers)
+    with pytest.raises(ValueError):
+        assign_keras_layers(PolicyValueNet(9, n_blocks=5, channels=8), layers)
+    with pytest.raises(ValueError):
+        assign_keras_layers(PolicyValueNet(9, n_blocks=5, channels=16), [l for l in layers if l[0] != "policy_out"])
