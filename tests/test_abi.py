@@ -67,3 +67,15 @@ def test_no_cpu_fallback_without_gpu():
         play.game_init(9)
     with pytest.raises(L.SgoError):
         play.legal_moves(np.zeros((1, 9, 9, 17), dtype=np.int32))
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/sgo.h is the drop-in boundary: it must compile as C99 (and as C++) on its own, no HIP or torch types."""
+    import subprocess
+    src = tmp_path / "t.c"
+    src.write_text('#include "sgo.h"\nint main(void) { return 0; }\n')
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", inc, str(src)])
+    subprocess.check_call(["g++", "-std=c++11", "-fsyntax-only", "-I", inc, "-x", "c++", str(src)])
+    hdr = open(os.path.join(inc, "sgo.h")).read()
+    assert "torch" not in hdr.lower().replace("pytorch", "") and "hip/" not in hdr
