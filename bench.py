@@ -13,8 +13,11 @@ network evaluations, 400 board_advance leaf positions and one move record per ga
               roofline_saturated = the same kernel family on a chip-filling dense batch
   cpu_baseline = the oracle (C restatement of the reference's rules + tree) driving the same net on torch
               CPU fp32, on a bounded sample, host cores stated ("kind": "port")
-Multi-GPU: one process per GPU, games sharded statically, no collective in the search; the per-step move
-records are gathered to rank 0 over RCCL inside the timed region (weak scaling).
+Multi-GPU: one process per GPU, games sharded statically, no collective in the search; the weights are broadcast
+from rank 0 once (RCCL) and the per-step move records are gathered to rank 0 over RCCL inside the timed region
+(weak scaling).  Launch: `python bench.py --gpus N` from a bare shell starts the N ranks itself (fresh interpreters,
+the launcher never touches a GPU; fewer than N visible devices is an error); under torch.distributed.run (RANK /
+WORLD_SIZE in the environment) the process is one rank.  N = 1 runs the same code with a one-rank process group.
 """
 import argparse
 import json
@@ -171,26 +174,44 @@ def saturated_advance(S, n=1 << 18, ply=60, iters=10):
             "inputs": "seeded random legal playouts, ply %d" % ply}
 
 
+def launcher(args):
+    """Bare-shell entry: start the ranks.  Nothing here initialises a GPU (device_count() only enumerates)."""
+    import torch
+    from sejonggo_amd.distributed import launch_ranks, free_port
+    n = args.gpus
+    ndev = torch.cuda.device_count()
+    if args.backend == "nccl" and ndev < n:
+        print("bench.py: --gpus %d needs %d HIP devices, %d visible (use --backend gloo to rehearse the N-rank path on "
+              "fewer devices)" % (n, n, ndev), file=sys.stderr)
+        return 2
+    if ndev < 1:
+        print("bench.py: no HIP device visible; the hot path has no CPU fallback", file=sys.stderr)
+        return 2
+    if n == 1:
+        os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
+        run_rank(args)
+        return 0
+    return launch_ranks([os.path.abspath(__file__)] + sys.argv[1:], n)
+
+
 def main():
     args = parse()
+    if "RANK" not in os.environ or "WORLD_SIZE" not in os.environ:
+        sys.exit(launcher(args))
+    if int(os.environ["WORLD_SIZE"]) != args.gpus:
+        print("bench.py: --gpus %d but WORLD_SIZE=%s" % (args.gpus, os.environ["WORLD_SIZE"]), file=sys.stderr)
+        sys.exit(2)
+    run_rank(args)
+
+
+def run_rank(args):
     import numpy as np
     import torch
     import torch.distributed as dist
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            torch.cuda.set_device(local)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:
-            local = local % torch.cuda.device_count()
-            torch.cuda.set_device(local)
-            dist.init_process_group("gloo")
-    else:
-        torch.cuda.set_device(0)
-        local = 0
+    from sejonggo_amd.distributed import init_from_env, broadcast_net
+    rank, world, local = init_from_env(args.backend)
+    if local is None:
+        raise SystemExit("bench.py: no HIP device visible; the hot path has no CPU fallback")
     from sejonggo_amd.engine import SelfPlayEngine
     from sejonggo_amd.net import build_net, build_fused_net
     from sejonggo_amd.stub_nets import make_stub
@@ -204,6 +225,10 @@ def main():
             net.split_streams = bool(args.split_streams)
     else:
         net = make_stub(args.net, S)
+    # replicas take their weights from rank 0 (one RCCL broadcast), checked identical by checksum
+    bcast = broadcast_net(net) if args.net == "resnet" else None
+    if bcast is not None and not bcast["identical"]:
+        raise SystemExit("bench.py: weight replicas differ after the broadcast")
     eng = SelfPlayEngine(net, size=S, n_games=G, sims=sims, energy=E, stop_exploration=30, symmetry=args.symmetry,
                          device=local, seed=1234 + rank)
     eng.start_games(np.arange(G))
@@ -230,8 +255,7 @@ def main():
         return gather_tuples(recs[:k])
 
     def sync():
-        if world > 1:
-            dist.barrier()
+        dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -250,8 +274,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     adv_ms, adv_n, adv_pos = eng.advance_timing()
     evals = eng.status.total_evals - evals0
@@ -284,7 +307,9 @@ def main():
                                    % (S, S, sims, E, G, ("random-init %d-block/%d-filter resnet fp16" % (args.blocks, args.channels))
                                       if args.net == "resnet" else args.net + " stub net", args.symmetry),
                        "games_per_gpu": G, "sims": sims, "energy": E, "net_evals_per_position": (sims // E) * E + 1,
-                       "sharding": "games g -> rank g mod N; RCCL gather of per-step records to rank 0"},
+                       "sharding": "games g -> rank g mod N; weights broadcast from rank 0; %s gather of per-step records to rank 0"
+                                   % ("RCCL" if args.backend == "nccl" else "gloo"),
+                       "backend": args.backend, "weights_broadcast": bcast},
             "roofline_board_advance": {"bound": "hbm", "kernel": "board_advance in situ (make_play + legal set + history move of the step's leaf list; k_board_advance_rows up to 32 768 leaves, k_board_advance above)",
                          "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": None, "algorithmic_bytes_per_position": ALGO_BYTES.get(S, 0),
@@ -335,9 +360,8 @@ def main():
                 out["cpu_baseline"] = {"value": None, "error": repr(ex)}
         print(json.dumps(out), flush=True)
     eng.close()
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -64,6 +64,16 @@ int sgo_make_play(int S, int n, int32_t *board17, const int32_t *xs, const int32
 int sgo_legal_moves(int S, int n, const int32_t *board17, uint8_t *mask);
 /* play.py:274-292 get_winner/_get_points: winner +1/0/-1, black points, white points (incl. komi) */
 int sgo_get_winner(int S, int n, const int32_t *board17, double komi, int32_t *winner, int32_t *black, double *white);
+/* play.py:182-217 take_stones on board tensors in place (planes 0/1 only): removes the opponent groups next to (x, y)
+ * that have no liberty, then the own groups among (x, y) and its four neighbours that have none (suicide executed). */
+int sgo_take_stones(int S, int n, int32_t *board17, const int32_t *xs, const int32_t *ys);
+/* Group / territory queries on plain boards (play.py:159-180 capture_group, :55-69 get_liberties, :244-271 color_board).
+ * cells int8 [n][S][S]: +1 black, -1 white, 0 empty, any other value = wall (neither stone nor liberty).
+ * mode 0: member[i] = the seed (xs[i], ys[i]) plus the stones of colour colors[i] connected to it; liberty[i] = empty
+ *         points next to a member.  mode 1: member[i] = empty points connected through empty points to a stone of
+ *         colour colors[i] (color_board's fill); liberty is zeroed.  member / liberty: uint8 [n][S][S]. */
+int sgo_board_query(int S, int n, int mode, const int8_t *cells, const int32_t *xs, const int32_t *ys, const int32_t *colors,
+                    uint8_t *member, uint8_t *liberty);
 /* symmetry.py:45-114 board transforms; k: 0 id, 1 left_diagonal, 2 vertical_axis, 3 horizontal_axis,
  * 4 rotation_90, 5 rotation_180, 6 rotation_270 (order of symmetry.SYMMETRIES, :117-125), 7 right_diagonal */
 int sgo_sym_apply(int S, int k, int n, const int32_t *in17, int32_t *out17);

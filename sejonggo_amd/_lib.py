@@ -17,7 +17,7 @@ SGO_ERR_RANGE = -102
 # every symbol include/sgo.h declares (tests/test_abi.py checks the built library exports them all)
 SYMBOLS = [
     "sgo_last_error", "sgo_version", "sgo_device_count", "sgo_set_device", "sgo_plane_words", "sgo_packed_words",
-    "sgo_apad", "sgo_game_init", "sgo_make_play", "sgo_legal_moves", "sgo_get_winner", "sgo_sym_apply",
+    "sgo_apad", "sgo_game_init", "sgo_make_play", "sgo_take_stones", "sgo_board_query", "sgo_legal_moves", "sgo_get_winner", "sgo_sym_apply",
     "sgo_sym_invert_policy", "sgo_sym_lut", "sgo_pack_dev", "sgo_unpack_dev", "sgo_advance_legal_dev",
     "sgo_legal_dev", "sgo_score_dev", "sgo_nn_pack_dev", "sgo_bias_act_dev", "sgo_conv3x3_bias_act_dev", "sgo_conv3x3_tower_dev", "sgo_conv_backend", "sgo_advance_mode", "sgo_ctx_create", "sgo_ctx_destroy", "sgo_start_games",
     "sgo_step", "sgo_collect", "sgo_drain_records", "sgo_game_results", "sgo_root_table", "sgo_tree_serialize", "sgo_tree_dump",
@@ -58,6 +58,7 @@ GAME_RESULT_DTYPE = np.dtype([("winner", "<i4"), ("black", "<i4"), ("white", "<f
                               ("n_moves", "<i4"), ("last_player", "<i4"), ("done", "<i4")], align=True)
 
 _lib = None
+gpu_touched_pid = None   # pid of the process in which this module first made a HIP call (fork-safety checks)
 
 
 def load():
@@ -95,8 +96,24 @@ def check(rc, what=""):
     return rc
 
 
+def gpu_runtime_initialised():
+    """True when THIS process has initialised a HIP runtime (through this library or through torch.cuda): a child
+    forked from it cannot use the GPU; start such children with the 'spawn' method instead."""
+    import sys
+    if gpu_touched_pid == os.getpid():
+        return True
+    torch = sys.modules.get("torch")
+    return bool(torch is not None and torch.cuda.is_initialized())
+
+
 def require_gpu():
+    global gpu_touched_pid
     lib = load()
+    if gpu_touched_pid is not None and gpu_touched_pid != os.getpid():
+        raise SgoError("this process was forked from one that had already initialised the GPU runtime; HIP does not "
+                       "survive a fork.  Start GPU workers before touching the GPU, or with the 'spawn' start method "
+                       "(sejonggo_amd.selfplay_worker does this by itself)")
+    gpu_touched_pid = os.getpid()
     if lib.sgo_device_count() <= 0:
         raise SgoError("no HIP device visible: the sejonggo_amd hot path runs on MI355X only (no CPU fallback)")
     return lib

@@ -2,7 +2,16 @@
 keys the self-play path reads; hosts/credentials of the reference's cluster config are not part of it)."""
 conf = {
     'MODEL_DIR': 'sp_models',
+    'EVAL_DIR': 'sp_eval_games',
     'SELF_PLAY_DIR': 'sp_self_play_data',
+    'LOG_DIR': 'logs',
+    'TMP_DIR': 'temp',
+    'GAMES_DIR': 'sp_eval_games',
+    'SIMULATION_MODE': "ASYNC",
+    'THREAD_SIMULATION': True,
+    'SLEEP_SECONDS': 120,
+    'EVALUATE_N_GAMES': 100,
+    'EVALUATE_MARGIN': .55,
     'BEST_MODEL': 'best_model.h5',
     'SHOW_EACH_MOVE': False,
     'SHOW_END_GAME': False,
@@ -28,6 +37,10 @@ conf = {
     'GAMES_PER_GPU': 1024,       # concurrent game slots resident on one MI355X
     'NET_DTYPE': 'fp16',
     'SYMMETRY_MODE': 'random1',  # 'random1' = reference behaviour (symmetry.py:127-132); 'avg8' = 8-fold averaging
+    'NET_CHANNELS': 256,         # filters of the tower (model.py:58 hard-codes 256)
     'COMPAT_Z': True,            # reproduce sgfsave.py:56 value_target quirk
+    'COMPAT_LATEST_SYM': True,   # reproduce predicting_queue_worker.py:92: LATEST_SYM requests are answered by the BEST model
+    'COMPAT_WINNER_MODEL': True, # reproduce nomodel_self_play.py:247: winner_model names the loser when model1 plays white
+    'SELFPLAY_WORKER_ENGINE': 'sync',  # SelfPlayWorker: 'sync' = self_play.model_self_play like the reference, 'device' = device engine
     'WRITE_NPZ_TWIN': True,      # without h5py: keep sample.npz beside the spec-written sample.h5
 }

@@ -217,6 +217,57 @@ SGO_DEV int advance_core(uint32_t (&own)[S], uint32_t (&opp)[S], int a) {
     return 0;
 }
 
+// take_stones (play.py:182-217) as a stand-alone step on a position that may or may not hold the stone at `a`:
+// pass 1 removes the opponent groups adjacent to `a` that have no liberty; pass 2 removes the own groups among the
+// four neighbours AND `a` itself that have no liberty.  With the stone present this equals advance_core minus the
+// placement; without it the (up to four) own neighbour groups are examined one by one, as the reference does.
+template <int S>
+SGO_DEV void take_core(uint32_t (&own)[S], uint32_t (&opp)[S], int a) {
+    constexpr uint32_t M = Geo<S>::ROWMASK;
+    const int my = a / S, mx = a - my * S;
+    uint32_t pb[S], np[S], emp[S], t[S], alive[S], dead[S], hit[S];
+#pragma unroll
+    for (int y = 0; y < S; y++) pb[y] = (y == my) ? (1u << mx) : 0u;
+    nbr4<S>(pb, np);
+#pragma unroll
+    for (int y = 0; y < S; y++) emp[y] = ~(own[y] | opp[y]) & M;
+    nbr4<S>(emp, t);
+#pragma unroll
+    for (int y = 0; y < S; y++) alive[y] = opp[y] & t[y];
+    flood<S>(alive, opp);
+    uint32_t any = 0;
+#pragma unroll
+    for (int y = 0; y < S; y++) {
+        dead[y] = opp[y] & ~alive[y];
+        hit[y] = dead[y] & np[y];
+        any |= hit[y];
+    }
+    if (any) {
+        flood<S>(hit, dead);
+#pragma unroll
+        for (int y = 0; y < S; y++) {
+            opp[y] &= ~hit[y];
+            emp[y] |= hit[y];
+        }
+    }
+    nbr4<S>(emp, t);
+#pragma unroll
+    for (int y = 0; y < S; y++) alive[y] = own[y] & t[y];
+    flood<S>(alive, own);
+    any = 0;
+#pragma unroll
+    for (int y = 0; y < S; y++) {
+        dead[y] = own[y] & ~alive[y];
+        hit[y] = dead[y] & (np[y] | pb[y]);
+        any |= hit[y];
+    }
+    if (any) {
+        flood<S>(hit, dead);
+#pragma unroll
+        for (int y = 0; y < S; y++) own[y] &= ~hit[y];
+    }
+}
+
 // ---- legal-move set --------------------------------------------------------------------------------
 // own = to-play stones (plane 0), opp = plane 1, prev = plane 2 (to-play side's stones one ply ago).
 // legal[] receives 1-bits for LEGAL board points (pass is handled by the caller).

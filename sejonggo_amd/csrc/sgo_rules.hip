@@ -270,6 +270,88 @@ __global__ __launch_bounds__(256) void k_score(int n, const uint32_t *packed, co
 // one block per board, one thread per point (rounded up to whole waves); wave ballots build the words.
 // The board tensor's planes are relative to the side to move (2k = to-play, 2k+1 = opponent); the record's are
 // absolute (2k = black, 2k+1 = white): relative plane c maps to absolute plane c ^ (white to play).
+// Group / territory queries on plain boards for the drop-in helpers play.capture_group / get_liberties / color_board
+// (play.py:55-69, :159-180, :244-271).  cells: int8 [n][S][S], +1 black, -1 white, 0 empty, anything else = wall (neither
+// a stone nor a liberty: used to embed smaller or rectangular arrays).  One lane per board.
+//   mode 0: member = the seed point plus every stone of colour `color` connected to it through stones of that colour;
+//           liberty = empty points next to a member (members themselves excluded)
+//   mode 1: member = empty points connected, through empty points, to a stone of colour `color` (color_board's fill)
+template <int S>
+__global__ __launch_bounds__(64) void k_board_query(int n, int mode, const int8_t *cells, const int32_t *xs, const int32_t *ys,
+                                                     const int32_t *colors, uint8_t *member, uint8_t *liberty) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int8_t *c = cells + (size_t)i * S * S;
+    uint32_t bl[S], wh[S], em[S], grp[S], lib[S], t[S];
+#pragma unroll
+    for (int y = 0; y < S; y++) {
+        uint32_t b = 0, w = 0, e = 0;
+        for (int x = 0; x < S; x++) {
+            const int v = c[y * S + x];
+            b |= (uint32_t)(v == 1) << x;
+            w |= (uint32_t)(v == -1) << x;
+            e |= (uint32_t)(v == 0) << x;
+        }
+        bl[y] = b; wh[y] = w; em[y] = e;
+    }
+    const int col = colors[i];
+    if (mode == 0) {
+        const int sx = xs[i], sy = ys[i];
+        uint32_t m[S];
+#pragma unroll
+        for (int y = 0; y < S; y++) {
+            grp[y] = (y == sy) ? (1u << sx) : 0u;
+            m[y] = (col == 1 ? bl[y] : col == -1 ? wh[y] : 0u) | grp[y];
+        }
+        flood<S>(grp, m);
+        nbr4<S>(grp, t);
+#pragma unroll
+        for (int y = 0; y < S; y++) lib[y] = t[y] & em[y] & ~grp[y];
+    } else {
+#pragma unroll
+        for (int y = 0; y < S; y++) t[y] = col == 1 ? bl[y] : wh[y];
+        nbr4<S>(t, grp);
+#pragma unroll
+        for (int y = 0; y < S; y++) {
+            grp[y] &= em[y];
+            lib[y] = 0;
+        }
+        flood<S>(grp, em);
+    }
+    uint8_t *mo = member + (size_t)i * S * S, *lo = liberty + (size_t)i * S * S;
+#pragma unroll
+    for (int y = 0; y < S; y++)
+        for (int x = 0; x < S; x++) {
+            mo[y * S + x] = (grp[y] >> x) & 1u;
+            lo[y * S + x] = (lib[y] >> x) & 1u;
+        }
+}
+
+// take_stones (play.py:182-217) on board tensors in place: planes 0 (to-play side) and 1 (opponent) only.
+template <int S>
+__global__ __launch_bounds__(64) void k_take_stones(int n, int32_t *boards, const int32_t *xs, const int32_t *ys) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int32_t *b = boards + (size_t)i * S * S * 17;
+    uint32_t own[S], opp[S];
+#pragma unroll
+    for (int y = 0; y < S; y++) {
+        uint32_t o = 0, p = 0;
+        for (int x = 0; x < S; x++) {
+            o |= (uint32_t)(b[(y * S + x) * 17] != 0) << x;
+            p |= (uint32_t)(b[(y * S + x) * 17 + 1] != 0) << x;
+        }
+        own[y] = o; opp[y] = p;
+    }
+    take_core<S>(own, opp, ys[i] * S + xs[i]);
+#pragma unroll
+    for (int y = 0; y < S; y++)
+        for (int x = 0; x < S; x++) {
+            if (!((own[y] >> x) & 1u)) b[(y * S + x) * 17] = 0;
+            if (!((opp[y] >> x) & 1u)) b[(y * S + x) * 17 + 1] = 0;
+        }
+}
+
 template <int S>
 __global__ void k_pack(int n, const int32_t *boards, uint32_t *packed) {
     using G = Geo<S>;
@@ -687,6 +769,58 @@ int sgo_get_winner(int S, int n, const int32_t *board17, double komi, int32_t *w
         if (black) black[i] = res[3 * i + 1];
         if (white) white[i] = (double)res[3 * i + 2] + komi;
     }
+    return SGO_OK;
+}
+
+int sgo_board_query(int S, int n, int mode, const int8_t *cells, const int32_t *xs, const int32_t *ys, const int32_t *colors,
+                    uint8_t *member, uint8_t *liberty) {
+    if (!size_ok(S) || n < 0 || (mode != 0 && mode != 1) || !cells || !colors || !member || !liberty || (mode == 0 && (!xs || !ys))) {
+        set_error("sgo_board_query: bad argument");
+        return SGO_ERR_ARG;
+    }
+    if (n == 0) return SGO_OK;
+    for (int i = 0; i < n; i++) {
+        if (mode == 0 && (xs[i] < 0 || xs[i] >= S || ys[i] < 0 || ys[i] >= S)) { set_error("sgo_board_query: seed outside the board"); return SGO_ERR_RANGE; }
+        if (colors[i] < -1 || colors[i] > 1 || (mode == 1 && colors[i] == 0)) { set_error("sgo_board_query: bad colour"); return SGO_ERR_ARG; }
+    }
+    std::lock_guard<std::mutex> lk(g_mu);
+    const size_t csz = (size_t)n * S * S;
+    int r;
+    if ((r = g_s[0].ensure(csz))) return r;
+    if ((r = g_s[1].ensure(2 * csz))) return r;
+    if ((r = g_s[2].ensure(sizeof(int32_t) * (size_t)n * 3))) return r;
+    int32_t *d_x = (int32_t *)g_s[2].p, *d_y = d_x + n, *d_c = d_x + 2 * n;
+    SGO_HIP(hipMemcpy(g_s[0].p, cells, csz, hipMemcpyHostToDevice));
+    if (mode == 0) {
+        SGO_HIP(hipMemcpy(d_x, xs, sizeof(int32_t) * n, hipMemcpyHostToDevice));
+        SGO_HIP(hipMemcpy(d_y, ys, sizeof(int32_t) * n, hipMemcpyHostToDevice));
+    }
+    SGO_HIP(hipMemcpy(d_c, colors, sizeof(int32_t) * n, hipMemcpyHostToDevice));
+    uint8_t *d_m = (uint8_t *)g_s[1].p, *d_l = d_m + csz;
+    SGO_DISPATCH(S, (k_board_query<kS><<<dim3((n + 63) / 64), dim3(64), 0, nullptr>>>(n, mode, (const int8_t *)g_s[0].p, d_x, d_y, d_c, d_m, d_l)));
+    SGO_HIP(hipGetLastError());
+    SGO_HIP(hipMemcpy(member, d_m, csz, hipMemcpyDeviceToHost));
+    SGO_HIP(hipMemcpy(liberty, d_l, csz, hipMemcpyDeviceToHost));
+    return SGO_OK;
+}
+
+int sgo_take_stones(int S, int n, int32_t *board17, const int32_t *xs, const int32_t *ys) {
+    if (!size_ok(S) || n < 0 || !board17 || !xs || !ys) { set_error("sgo_take_stones: bad argument"); return SGO_ERR_ARG; }
+    if (n == 0) return SGO_OK;
+    for (int i = 0; i < n; i++)
+        if (xs[i] < 0 || xs[i] >= S || ys[i] < 0 || ys[i] >= S) { set_error("sgo_take_stones: point outside the board"); return SGO_ERR_RANGE; }
+    std::lock_guard<std::mutex> lk(g_mu);
+    const size_t bsz = sizeof(int32_t) * (size_t)n * S * S * 17;
+    int r;
+    if ((r = g_s[0].ensure(bsz))) return r;
+    if ((r = g_s[2].ensure(sizeof(int32_t) * (size_t)n * 2))) return r;
+    int32_t *d_x = (int32_t *)g_s[2].p, *d_y = d_x + n;
+    SGO_HIP(hipMemcpy(g_s[0].p, board17, bsz, hipMemcpyHostToDevice));
+    SGO_HIP(hipMemcpy(d_x, xs, sizeof(int32_t) * n, hipMemcpyHostToDevice));
+    SGO_HIP(hipMemcpy(d_y, ys, sizeof(int32_t) * n, hipMemcpyHostToDevice));
+    SGO_DISPATCH(S, (k_take_stones<kS><<<dim3((n + 63) / 64), dim3(64), 0, nullptr>>>(n, (int32_t *)g_s[0].p, d_x, d_y)));
+    SGO_HIP(hipGetLastError());
+    SGO_HIP(hipMemcpy(board17, g_s[0].p, bsz, hipMemcpyDeviceToHost));
     return SGO_OK;
 }
 

@@ -1,11 +1,19 @@
 """Multi-GPU side of the path: games shard statically over ranks (one process per GPU, no exchange during
-search); the only collective is the gather of finished (s, pi, z) tuples to rank 0 (SURVEY.md §8e --
-the reference ships files by scp, scpy.py:68-76).  Works on RCCL (backend "nccl", CUDA tensors) and on
-gloo (CPU tensors, used by the world_size-2 CPU tests).
+search); the collectives are (1) one broadcast of the network weights from rank 0 when the replicas are set up and
+(2) the gather of finished (s, pi, z) tuples to rank 0 (SURVEY.md §8e -- the reference ships files by scp,
+scpy.py:68-76).  Works on RCCL (backend "nccl", CUDA tensors) and on gloo (CPU tensors; the world_size-2 CPU tests).
 
 Variable-length gather: all_gather of one int64 count per rank, then dist.gather of max-padded uint8
 blocks (on the 8-GPU xGMI mesh that is 7 concurrent point-to-point transfers into rank 0, a few MB at
-most, far below one link's bandwidth), then rank 0 trims the padding."""
+most, far below one link's bandwidth), then rank 0 trims the padding.
+
+`launch_ranks` starts one fresh interpreter per rank (never a fork of a process that may hold a GPU) with the
+torch.distributed environment set; bench.py --gpus N and the tests use it."""
+import os
+import socket
+import subprocess
+import sys
+
 import numpy as np
 
 
@@ -23,16 +31,94 @@ def shard_games(n_games_total, world_size, rank):
     return [g for g in range(n_games_total) if g % world_size == rank]
 
 
-def gather_tuples(tuples, device=None, dst=0):
-    """tuples: numpy structured array (tuple_dtype) of this rank.  Returns the concatenation over ranks on
-    rank `dst` (rank order), None elsewhere.  Single-process runs return the input."""
+# ---------------------------------------------------------------------------------------------- process launch
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(argv, n_ranks, env=None, timeout=None, master_port=None):
+    """Runs `python argv...` once per rank with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, each in
+    a fresh interpreter.  The caller's stdout / stderr are inherited (rank 0 prints the result line).  Returns 0, or
+    the exit code of the first rank that failed (the others are then terminated), or 124 on timeout."""
+    port = master_port or free_port()
+    procs = []
+    for r in range(n_ranks):
+        e = dict(os.environ if env is None else env)
+        e.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable] + list(argv), env=e))
+    import time
+    t0 = time.time()
+    codes = [None] * n_ranks
+    while any(c is None for c in codes):
+        for i, p in enumerate(procs):
+            if codes[i] is None:
+                codes[i] = p.poll()
+        failed = any(c not in (None, 0) for c in codes)
+        timed_out = timeout is not None and time.time() - t0 > timeout
+        if failed or timed_out:
+            first = next((abs(c) for c in codes if c not in (None, 0)), 0)
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    p.terminate()
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    try:
+                        codes[i] = p.wait(10)
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        codes[i] = p.wait()
+            return first if failed else 124
+        time.sleep(0.05)
+    return max(abs(c) for c in codes)
+
+
+def init_from_env(backend="nccl"):
+    """Initialises torch.distributed from the launcher's environment.  nccl (= RCCL): this rank's device is
+    LOCAL_RANK and must exist; gloo: ranks may share devices (LOCAL_RANK mod device count; CPU-only hosts work too).
+    Returns (rank, world, local_device or None)."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(free_port() if world == 1 else 29500))
+    ndev = torch.cuda.device_count()
+    if backend == "nccl":
+        if local >= ndev:
+            raise RuntimeError("rank %d needs device %d but only %d HIP device(s) are visible" % (rank, local, ndev))
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        return rank, world, local
+    dev = (local % ndev) if ndev > 0 else None
+    if dev is not None:
+        torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    return rank, world, dev
+
+
+def _comm_device():
+    import torch
+    import torch.distributed as dist
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
+# ---------------------------------------------------------------------------------------------- collectives
+def gather_tuples(tuples, device=None, dst=0):
+    """tuples: numpy structured array (tuple_dtype) of this rank.  Returns the concatenation over ranks on
+    rank `dst` (rank order), None elsewhere.  Without an initialised process group the input is returned; with
+    one -- world size 1 included -- the collectives run."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
         return tuples
     world, rank = dist.get_world_size(), dist.get_rank()
-    dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device())
-                                             if dist.get_backend() == "nccl" else torch.device("cpu"))
+    dev = device if device is not None else _comm_device()
     itemsize = tuples.dtype.itemsize
     cnt = torch.tensor([len(tuples)], dtype=torch.int64, device=dev)
     counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
@@ -50,3 +136,53 @@ def gather_tuples(tuples, device=None, dst=0):
         return np.concatenate(parts) if parts else tuples[:0]
     dist.gather(buf, None, dst=dst)
     return None
+
+
+def net_tensors(net):
+    """The weight tensors of a resident net (net.FusedInferenceNet or a torch module), in a fixed order."""
+    import torch
+    if hasattr(net, "parameters"):
+        return [p.data for p in net.parameters()] + [b.data for b in net.buffers()]
+    out = []
+    for name in ("stem_w", "stem_b"):
+        out.append(getattr(net, name))
+    for blk in getattr(net, "blocks", []):
+        out.extend(blk)
+    for name in ("head_w", "head_b", "p_fc_w", "p_fc_b", "v_fc1_w", "v_fc1_b", "v_fc2_w", "v_fc2_b"):
+        out.append(getattr(net, name))
+    return [t for t in out if torch.is_tensor(t)]
+
+
+def _checksum(tensors):
+    import torch
+    total = 0
+    for t in tensors:
+        b = t.detach().contiguous().reshape(-1).view(torch.uint8).to(torch.int64)
+        total = (total * 1000003 + int(b.sum().item()) + 31 * int((b * (torch.arange(b.numel(), device=b.device) % 251 + 1)).sum().item())) % (1 << 61)
+    return total
+
+
+def broadcast_net(net, src=0):
+    """the replicas' weights come from rank `src` (one broadcast per tensor, ~47 MB for the 20-block
+    net), then every rank's checksum is compared so the replicas are provably identical.  Returns
+    {"bytes", "tensors", "checksum", "identical"}; without a process group nothing is sent."""
+    import torch
+    import torch.distributed as dist
+    ts = net_tensors(net)
+    nbytes = sum(t.numel() * t.element_size() for t in ts)
+    if not (dist.is_available() and dist.is_initialized()):
+        return {"bytes": nbytes, "tensors": len(ts), "checksum": _checksum(ts), "identical": True}
+    on_cpu = dist.get_backend() != "nccl"
+    for t in ts:
+        if on_cpu and t.is_cuda:
+            c = t.detach().cpu()
+            dist.broadcast(c, src=src)
+            t.copy_(c)
+        else:
+            dist.broadcast(t, src=src)
+    cs = _checksum(ts)
+    mine = torch.tensor([cs], dtype=torch.int64, device=_comm_device())
+    alls = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(alls, mine)
+    same = all(int(a.item()) == cs for a in alls)
+    return {"bytes": nbytes, "tensors": len(ts), "checksum": cs, "identical": same}

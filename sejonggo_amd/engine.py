@@ -123,7 +123,8 @@ class SelfPlayEngine(object):
         uniforms = np.ascontiguousarray(uniforms, dtype=np.float64).reshape(n, -1)
         res = None
         if resign is not None:
-            res = np.array([np.nan if r is None else r for r in resign], dtype=np.float32)
+            # `if resign and value <= resign` (nomodel_self_play.py:171): None AND 0.0 mean "never resign"
+            res = np.array([np.nan if not r else r for r in resign], dtype=np.float32)
         _lib.check(self.lib.sgo_start_games(self.ctx, C.c_int(n), _lib.ptr(slots), _lib.ptr(noises), _lib.ptr(uniforms),
                                             C.c_int(uniforms.shape[1]), _lib.ptr(res)), "sgo_start_games")
         for i, s in enumerate(slots):
@@ -321,52 +322,3 @@ class SelfPlayEngine(object):
         ms, n, p = C.c_double(0), C.c_int64(0), C.c_int64(0)
         _lib.check(self.lib.sgo_advance_timing(self.ctx, C.byref(ms), C.byref(n), C.byref(p)), "sgo_advance_timing")
         return ms.value, n.value, p.value
-
-
-def smoke_selfplay():
-    """Tiny end-to-end run on cuda:0: the rounding-free HashNet game must reproduce the oracle's game
-    move for move and tree for tree; then a random-init resnet plays a few moves for structural sanity."""
-    import hashlib
-    import torch
-    from oracle import oracle as ora
-    from .stub_nets import make_stub
-    from .net import PolicyValueNet
-    S, sims, E = 9, 48, 8
-    rng = np.random.RandomState(3)
-    noise = rng.dirichlet([0.03] * (S * S + 1), size=1)
-    uni = rng.random_sample((1, 2 * S * S))
-    stub = make_stub("hash", S)
-    eng = SelfPlayEngine(stub, size=S, n_games=1, sims=sims, energy=E, stop_exploration=6, num_moves=10, komi=5.5,
-                         symmetry="identity", dtype="fp16")
-    eng.start_games([0], noises=noise, uniforms=uni)
-    games = eng.run()
-    g = ora.Game(S, sims, E, 6, 10, uniforms=uni[0], noises=noise).run(stub)
-    assert len(games) == 1 and len(games[0]['moves']) == g.n_moves == 10
-    for i, mv in enumerate(games[0]['moves']):
-        m = g.move(i)
-        assert mv['move'][0] + S * mv['move'][1] == m['action'] or (mv['move'][1] == S and m['action'] == S * S)
-        assert np.array_equal(mv['board'], m['board']) and mv['policy'].tobytes() == m['policy'].tobytes()
-    ta, _, _ = eng.tree_serialize(0)
-    tb, _, _ = g.tree_serialize()
-    assert hashlib.sha1(ta.tobytes()).digest() == hashlib.sha1(tb.tobytes()).digest(), "tree mismatch vs oracle"
-    eng.close()
-    net = PolicyValueNet(S, n_blocks=2, channels=32, name="smoke").cuda().half().eval()
-    eng = SelfPlayEngine(net, size=S, n_games=8, sims=16, energy=8, stop_exploration=2, num_moves=3, symmetry="random1")
-    eng.start_games(np.arange(8))
-    games = eng.run()
-    assert len(games) == 8 and all(len(gd['moves']) == 3 for gd in games)
-    eng.close()
-    # the production net form: FusedInferenceNet on the hand-written tower convolution, against its own fp32 torch module
-    from .net import build_fused_net
-    fnet, ref = build_fused_net(S, 2, 256, name="smoke256", seed=1, device="cuda")
-    x = torch.zeros((24, S, S, 17), dtype=torch.float16, device="cuda")
-    x[..., :16] = (torch.rand((24, S, S, 16), device="cuda") < 0.2).half()
-    x[..., 16] = 1.0
-    p1, v1 = fnet.predict_on_batch(x)
-    p0, v0 = ref.float().cuda().predict_on_batch(x.float())
-    assert float((p1 - p0).abs().max()) <= 2e-3 and float((v1 - v0).abs().max()) <= 5e-3, "fused net vs fp32 module"
-    eng = SelfPlayEngine(fnet, size=S, n_games=8, sims=16, energy=8, stop_exploration=2, num_moves=3, symmetry="random1")
-    eng.start_games(np.arange(8))
-    games = eng.run()
-    assert len(games) == 8 and all(len(gd['moves']) == 3 for gd in games)
-    eng.close()

@@ -85,6 +85,20 @@ def assign_keras_layers(net, layers):
     return net
 
 
+def keras_model_name(path):
+    """`model.name` of a Keras model file: the `name` of its `model_config` attribute (model.py:92 builds the model with
+    an explicit name and train.py renames it before saving).  None for a weights-only file.  Needs h5py."""
+    import json
+    import h5py
+    with h5py.File(path, "r") as f:
+        cfg = f.attrs.get("model_config")
+    if cfg is None:
+        return None
+    if isinstance(cfg, bytes):
+        cfg = cfg.decode()
+    return json.loads(cfg).get("config", {}).get("name")
+
+
 def load_keras_h5(path, net):
     """Read a Keras model / weights file and assign it to `net`.  Needs h5py."""
     import h5py   # noqa: F401 -- deliberately not optional: there is no other reader for Keras' classic-format files here

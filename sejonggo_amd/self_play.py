@@ -87,3 +87,55 @@ def play_game(model1, model2, mcts_simulations, stop_exploration, self_play=Fals
 
     return play_loop(conf['SIZE'], first, second, evaluate, choose, lambda m: m.name, stop_exploration, self_play=self_play,
                      num_moves=num_moves, resign_first=r_first, resign_second=r_second, first_is_model1=not swap)
+
+
+def _resign_bookkeeping(game_data, resign, min_values, current_resign):
+    """self_play.py:318-329: only no-resign games calibrate the threshold; min_values stays in arrival order."""
+    if resign is None:
+        moves = game_data['moves']
+        own = moves[::2] if game_data['winner'] == 1 else moves[1::2]
+        min_values.append(min([m['value'] for m in own]))
+        idx = int(conf['RESIGNATION_ALLOWED_ERROR'] * len(min_values))
+        if idx > 0:
+            current_resign = min_values[idx]
+    return current_resign
+
+
+def model_self_play(model, one_game_only=-1):
+    """self_play.py:292-339: N_GAMES sync self-play games of `model`, skipping game numbers whose directory exists;
+    `one_game_only` >= 0 plays exactly that game number."""
+    import os
+    from random import random
+    from .sgfsave import save_self_play_data
+    games_data, current_resign, min_values = [], None, []
+    for game in range(conf['N_GAMES']):
+        if 0 <= one_game_only and game != one_game_only:
+            continue
+        directory = os.path.join(conf['SELF_PLAY_DIR'], model.name, "game_%05d" % game)
+        if os.path.isdir(directory):
+            continue
+        os.makedirs(directory)
+        resign = current_resign if random() > conf['RESIGNATION_PERCENT'] else None
+        game_data = play_game(model, model, conf['MCTS_SIMULATIONS'], conf['STOP_EXPLORATION'], self_play=True,
+                              resign_model1=resign, resign_model2=resign)
+        current_resign = _resign_bookkeeping(game_data, resign, min_values, current_resign)
+        save_self_play_data(model.name, game, game_data)
+        games_data.append(game_data)
+        if one_game_only >= 0:
+            break
+    return games_data
+
+
+def self_play(model, n_games, mcts_simulations):
+    """self_play.py:342-379: n_games sync self-play games saved with save_game_data (GAMES_DIR)."""
+    from random import random
+    from .sgfsave import save_game_data
+    games_data, current_resign, min_values = [], None, []
+    for game in range(n_games):
+        resign = current_resign if random() > conf['RESIGNATION_PERCENT'] else None
+        game_data = play_game(model, model, mcts_simulations, conf['STOP_EXPLORATION'], self_play=True,
+                              resign_model1=resign, resign_model2=resign)
+        current_resign = _resign_bookkeeping(game_data, resign, min_values, current_resign)
+        save_game_data(model.name, game, game_data)
+        games_data.append(game_data)
+    return games_data

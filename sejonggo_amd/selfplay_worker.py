@@ -3,12 +3,24 @@ SelfPlayWorker(gpuid, forever=False, one_game_only=-1) are multiprocessing.Proce
 reference's start()/join() life cycle, game-directory reservation (selfplay_worker.py:83-90), resign-
 threshold calibration (:92-112) and zero-move clean-up (:115-118).
 
-Difference in kind, not in contract: the reference runs ONE game per process (and 8 pool workers under it);
-here one process drives ONE MI355X that keeps conf['GAMES_PER_GPU'] games resident, reserving the next free
-game directory whenever a slot finishes.  Run one worker per GPU (conf['N_GAME_PROCESS'] = number of GPUs)."""
+NoModelSelfPlayWorker -- difference in kind, not in contract: the reference runs ONE game per process (and 8 pool
+workers under it); here one process drives ONE MI355X that keeps conf['GAMES_PER_GPU'] games resident, reserving the
+next free game directory whenever a slot finishes.  Run one worker per GPU (conf['N_GAME_PROCESS'] = number of GPUs).
+
+SelfPlayWorker follows selfplay_worker.py:29-58 literally: load the best model, play self_play.model_self_play (the
+sync path, one game at a time, game number `one_game_only` when >= 0), and with `forever` keep reloading the best model,
+sleeping conf['SLEEP_SECONDS'] while it has not changed.  conf['SELFPLAY_WORKER_ENGINE'] = 'device' swaps the sync
+game loop for the many-games device engine (same files on disk, far higher throughput; not the reference's search).
+
+Processes and the GPU.  A child forked from a process that has initialised a HIP runtime cannot use the GPU.  The
+workers therefore start by fork (the reference's behaviour: conf and module state are inherited) only while the
+parent is GPU-free -- which main_selfplay.main() guarantees -- and by 'spawn' otherwise, carrying a snapshot of
+conf (and of a picklable model factory) into the fresh interpreter."""
 import os
 import sys
+import time
 import traceback
+import multiprocessing
 from multiprocessing import Process
 from random import random
 
@@ -21,8 +33,9 @@ class GameScheduler(object):
     """Host logic shared by both workers: which game number a free slot plays next, and the resign
     threshold (selfplay_worker.py:82-112).  Pure bookkeeping; no compute."""
 
-    def __init__(self, self_play_dir, model_name, n_games, resignation_percent, allowed_error, rand=random):
+    def __init__(self, self_play_dir, model_name, n_games, resignation_percent, allowed_error, rand=random, only_game=None):
         self.dir, self.model_name, self.n_games = self_play_dir, model_name, n_games
+        self.only_game = only_game     # self_play.py:303-304: `one_game_only` plays exactly that game number
         self.resignation_percent, self.allowed_error = resignation_percent, allowed_error
         self.rand = rand
         self.next_game = 0
@@ -34,6 +47,8 @@ class GameScheduler(object):
         while self.next_game < self.n_games:
             g = self.next_game
             self.next_game += 1
+            if self.only_game is not None and g != self.only_game:
+                continue
             directory = os.path.join(self.dir, self.model_name, "game_%05d" % g)
             if os.path.isdir(directory):
                 continue
@@ -66,7 +81,8 @@ class GameScheduler(object):
             pass
 
 
-def run_selfplay(gpu_id, model_indicator="BEST_SYM", n_games=None, games_per_gpu=None, on_game=None, max_steps=None):
+def run_selfplay(gpu_id, model_indicator="BEST_SYM", n_games=None, games_per_gpu=None, on_game=None, max_steps=None,
+                 only_game=None):
     """The worker body, callable in-process (tests, bench) as well as from the Process subclasses."""
     from .engine import SelfPlayEngine
     from .predicting_queue_worker import init_predicting_workers, get_model, put_name_request
@@ -75,9 +91,9 @@ def run_selfplay(gpu_id, model_indicator="BEST_SYM", n_games=None, games_per_gpu
     net = get_model(model_indicator, gpu_id)
     model_name = put_name_request(model_indicator)
     n_games = conf['N_GAMES'] if n_games is None else n_games
-    G = min(games_per_gpu or conf['GAMES_PER_GPU'], max(1, n_games))
+    G = min(games_per_gpu or conf['GAMES_PER_GPU'], max(1, n_games if only_game is None else 1))
     sched = GameScheduler(conf['SELF_PLAY_DIR'], model_name, n_games, conf['RESIGNATION_PERCENT'],
-                          conf['RESIGNATION_ALLOWED_ERROR'])
+                          conf['RESIGNATION_ALLOWED_ERROR'], only_game=only_game)
     sym = conf.get('SYMMETRY_MODE', 'random1') if model_indicator.endswith("_SYM") else "identity"
     eng = SelfPlayEngine(net, size=conf['SIZE'], n_games=G, sims=conf['MCTS_SIMULATIONS'], energy=conf['ENERGY'],
                          stop_exploration=conf['STOP_EXPLORATION'], komi=conf['KOMI'], self_play=True, symmetry=sym,
@@ -149,13 +165,39 @@ def run_selfplay(gpu_id, model_indicator="BEST_SYM", n_games=None, games_per_gpu
     return played
 
 
-class NoModelSelfPlayWorker(Process):
+class _GpuWorker(Process):
+    """multiprocessing.Process whose child may use the GPU whatever the parent did before start()."""
+
+    def start(self):
+        from . import predicting_queue_worker as pq
+        self._conf_snapshot = dict(conf)
+        self._factory_snapshot = pq._factory
+        return Process.start(self)
+
+    @staticmethod
+    def _Popen(process_obj):
+        from . import _lib
+        method = 'spawn' if _lib.gpu_runtime_initialised() else None
+        return multiprocessing.get_context(method).Process._Popen(process_obj)
+
+    def _enter_child(self):
+        """Under 'spawn' the interpreter is fresh: restore what a fork would have inherited."""
+        from . import predicting_queue_worker as pq
+        snap = getattr(self, '_conf_snapshot', None)
+        if snap is not None:
+            conf.update(snap)
+        if pq._factory is None and getattr(self, '_factory_snapshot', None) is not None:
+            pq.set_model_factory(self._factory_snapshot)
+
+
+class NoModelSelfPlayWorker(_GpuWorker):
     def __init__(self, process_id):
         Process.__init__(self, name='SelfPlayProcessor')
         self._process_id = process_id
 
     def run(self):
         try:
+            self._enter_child()
             gpus = conf['GPUs']
             run_selfplay(gpus[self._process_id % len(gpus)], "BEST_SYM")
         except Exception as e:  # the reference prints and carries on (selfplay_worker.py:126-130)
@@ -163,17 +205,49 @@ class NoModelSelfPlayWorker(Process):
             traceback.print_exc(file=sys.stdout)
 
 
-class SelfPlayWorker(Process):
+class SelfPlayWorker(_GpuWorker):
     def __init__(self, gpuid, forever=False, one_game_only=-1):
         Process.__init__(self, name='SelfPlayProcessor')
         self._gpuid = gpuid
         self._forever = forever
         self._one_game_only = one_game_only
 
+    def _play(self, model):
+        if conf.get('SELFPLAY_WORKER_ENGINE', 'sync') == 'device':
+            n = conf['N_GAMES']
+            only = self._one_game_only if self._one_game_only >= 0 else None
+            return run_selfplay(self._gpuid, "BEST", n_games=n, only_game=only)
+        from .self_play import model_self_play
+        from .predicting_queue_worker import _NumpyNet
+        # the sync game loop is host code on numpy boards (like the reference's, which talks to Keras): the resident
+        # net is presented through the numpy face of the model contract
+        return model_self_play(_NumpyNet(model), one_game_only=self._one_game_only)
+
     def run(self):
+        """selfplay_worker.py:29-58."""
         try:
-            n = 1 if self._one_game_only >= 0 else None
-            run_selfplay(self._gpuid, "BEST", n_games=n)
+            self._enter_child()
+            from .predicting_queue_worker import init_predicting_workers, destroy_predicting_workers, get_model
+            from .simulation_workers import init_simulation_workers, destroy_simulation_workers
+            if conf.get('THREAD_SIMULATION', True):
+                init_simulation_workers()
+            init_predicting_workers([self._gpuid])
+            name = ""
+            model = get_model("BEST", self._gpuid)
+            while True:
+                if model.name != name:
+                    name = model.name
+                    self._play(model)
+                else:
+                    print("No new best model")
+                    if self._forever:
+                        time.sleep(conf.get('SLEEP_SECONDS', 120))
+                if not self._forever:
+                    break
+                destroy_predicting_workers([self._gpuid])       # drop the resident copy: reload from MODEL_DIR
+                init_predicting_workers([self._gpuid])
+                model = get_model("BEST", self._gpuid)
+            destroy_simulation_workers()
         except Exception as e:
             print("EXCEPTION in SelfPlayWorker!!!: %s" % e)
             traceback.print_exc(file=sys.stdout)

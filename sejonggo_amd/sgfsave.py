@@ -31,27 +31,100 @@ def value_target(winner, player, move_n, compat=None):
     return 1 if mover_is_black == black_won else -1
 
 
+def _write_sample(directory, move_data, winner):
+    vt = value_target(winner, move_data['player'], move_data['move_n'])
+    board = np.asarray(move_data['board'], dtype=np.float32)
+    pol = np.asarray(move_data['policy'], dtype=np.float32)
+    val = np.array(vt, dtype=np.float32)
+    if HAVE_H5:
+        import h5py
+        with h5py.File(os.path.join(directory, 'sample.h5'), 'w') as f:
+            f.create_dataset('board', data=board, dtype=np.float32)
+            f.create_dataset('policy_target', data=pol, dtype=np.float32)
+            f.create_dataset('value_target', data=val, dtype=np.float32)
+    else:
+        from .hdf5_min import write_datasets
+        write_datasets(os.path.join(directory, 'sample.h5'),
+                       {'board': board, 'policy_target': pol, 'value_target': val})
+        if conf.get('WRITE_NPZ_TWIN', True):
+            np.savez(os.path.join(directory, 'sample.npz'), board=board, policy_target=pol, value_target=val)
+
+
+def _make_move_dir(root, model_name, pattern, game_no, move_n):
+    """sgfsave.py:23-33 / :59-73: a move directory that already exists means another writer owns that game number;
+    the reference then bumps the game number until the directory can be created (and keeps the bumped number for the
+    rest of the game)."""
+    while True:
+        directory = os.path.join(root, model_name, pattern % game_no, "move_%03d" % move_n)
+        try:
+            os.makedirs(directory)
+            return directory, game_no
+        except OSError:
+            game_no += 1
+
+
 def save_self_play_data(model_name, game_no, game_data):
+    """sgfsave.py:49-79."""
     winner = game_data['winner']
     for move_data in game_data['moves']:
-        vt = value_target(winner, move_data['player'], move_data['move_n'])
-        directory = os.path.join(conf['SELF_PLAY_DIR'], model_name, "game_%05d" % game_no, "move_%03d" % move_data['move_n'])
-        os.makedirs(directory, exist_ok=True)
-        board = np.asarray(move_data['board'], dtype=np.float32)
-        pol = np.asarray(move_data['policy'], dtype=np.float32)
-        val = np.array(vt, dtype=np.float32)
-        if HAVE_H5:
-            import h5py
-            with h5py.File(os.path.join(directory, 'sample.h5'), 'w') as f:
-                f.create_dataset('board', data=board, dtype=np.float32)
-                f.create_dataset('policy_target', data=pol, dtype=np.float32)
-                f.create_dataset('value_target', data=val, dtype=np.float32)
-        else:
-            from .hdf5_min import write_datasets
-            write_datasets(os.path.join(directory, 'sample.h5'),
-                           {'board': board, 'policy_target': pol, 'value_target': val})
-            if conf.get('WRITE_NPZ_TWIN', True):
-                np.savez(os.path.join(directory, 'sample.npz'), board=board, policy_target=pol, value_target=val)
+        directory, game_no = _make_move_dir(conf['SELF_PLAY_DIR'], model_name, "game_%05d", game_no, move_data['move_n'])
+        _write_sample(directory, move_data, winner)
+    if conf.get('SGF_ENABLED'):
+        save_game_sgf(model_name, game_no, game_data)
+
+
+def save_file(model_name, game_n, move_data, winner, game_name="game"):
+    """sgfsave.py:16-38: one move of an evaluation / plain game under conf['GAMES_DIR']."""
+    directory, _ = _make_move_dir(conf['GAMES_DIR'], model_name, game_name + "_%03d", game_n, move_data['move_n'])
+    _write_sample(directory, move_data, winner)
+
+
+def save_game_data(model_name, game_n, game_data, game_name="game"):
+    """sgfsave.py:41-46."""
+    winner = game_data['winner']
+    for move_data in game_data['moves']:
+        save_file(model_name, game_n, move_data, winner, game_name)
+    if conf.get('SGF_ENABLED'):
+        save_game_sgf(model_name, game_n, game_data)
+
+
+def _sgf_point(x, y, size):
+    """SGF coordinates of the reference's (x, y); its files come out of sgfmill with row 0 at the top, so the point
+    written for (x, y) is column x, row y counted from the top (sgfsave.py:141: `(SIZE - 1 - y, x)` in sgfmill's
+    bottom-up rows)."""
+    if y == size:
+        return ""
+    return "abcdefghijklmnopqrs"[x] + "abcdefghijklmnopqrs"[y]
+
+
+def save_game_sgf(model_name, game_n, game_data):
+    """sgfsave.py:129-167 without sgfmill: the same properties (PB, PW, KM, RE, one B[]/W[] node per move with the
+    value comment) serialised directly.  Parity unpinned: sgfmill is absent here, so the byte-level layout of its
+    serialiser (line folding, property order beyond FF/GM/SZ) is not reproduced."""
+    size = conf['SIZE']
+    from .play import get_real_board
+
+    def esc(t):
+        return t.replace("\\", "\\\\").replace("]", "\\]")
+
+    out = ["(;FF[4]GM[1]SZ[%d]PB[%s]PW[%s]KM[%s]RE[%s]" % (size, esc(game_data['modelB_name']), esc(game_data['modelW_name']),
+                                                          conf['KOMI'], esc(game_data['result']))]
+    moves = game_data['moves']
+    for move_data in moves:
+        color = 'B' if move_data['player'] == 1 else 'W'
+        x, y = move_data['move']
+        nxt = moves[(move_data['move_n'] + 1) % len(moves)]['board']
+        comment = "Value %s\n %s" % (move_data['value'], get_real_board(nxt))
+        out.append(";%s[%s]C[%s]" % (color, _sgf_point(x, y, size), esc(comment)))
+    out.append(")\n")
+    os.makedirs(os.path.join(conf['GAMES_DIR'], model_name), exist_ok=True)
+    filename = os.path.join(conf['GAMES_DIR'], model_name, "game_%03d.sgf" % game_n)
+    while os.path.isfile(filename):
+        game_n += 1
+        filename = os.path.join(conf['GAMES_DIR'], model_name, "game_%03d.sgf" % game_n)
+    with open(filename, "wb") as f:
+        f.write("".join(out).encode("utf-8"))
+    return filename
 
 
 def convert_npz_to_h5(root):

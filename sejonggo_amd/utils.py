@@ -7,19 +7,28 @@ from .conf import conf
 
 
 def init_directories():
-    for k in ('MODEL_DIR', 'SELF_PLAY_DIR'):
-        os.makedirs(conf[k], exist_ok=True)
+    """utils.py:117-145 (the conf-named directories; the reference also makes a bare ./logs)."""
+    for d in (conf['MODEL_DIR'], conf['LOG_DIR'], conf['EVAL_DIR'], conf['SELF_PLAY_DIR'],
+              os.path.join(conf['SELF_PLAY_DIR'], "KGS"), conf['TMP_DIR']):
+        try:
+            os.makedirs(d)
+        except OSError:
+            pass
 
 
 def clean_up_empty():
-    root = conf['SELF_PLAY_DIR']
-    if not os.path.isdir(root):
-        return
-    for model in os.listdir(root):
-        mdir = os.path.join(root, model)
-        if not os.path.isdir(mdir):
-            continue
-        for game in os.listdir(mdir):
-            gdir = os.path.join(mdir, game)
-            if os.path.isdir(gdir) and not os.listdir(gdir):
-                os.rmdir(gdir)
+    """utils.py:147-160: remove reserved-but-empty game directories under EVAL_DIR and SELF_PLAY_DIR."""
+    try:
+        for folder in (conf['EVAL_DIR'], conf['SELF_PLAY_DIR']):
+            for _dir in os.listdir(folder):
+                dir_path = os.path.join(folder, _dir)
+                if not os.path.isdir(dir_path):
+                    continue
+                for d in os.listdir(dir_path):
+                    d_path = os.path.join(dir_path, d)
+                    if os.path.isdir(d_path) and len(os.listdir(d_path)) == 0:
+                        print("Clean up empty dir", d_path)
+                        os.rmdir(d_path)
+    except Exception as e:
+        print("EXCEPTION WHILE CLEANING FOLDERS!!")
+        print(e)

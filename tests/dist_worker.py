@@ -1,0 +1,48 @@
+"""One rank of the multi-process tests (started by sejonggo_amd.distributed.launch_ranks, the same launcher bench.py
+--gpus N uses): gathers ragged (s, pi, z) tuples to rank 0 and takes the network weights from rank 0.
+usage: dist_worker.py <backend> <out_dir>"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    backend, out_dir = sys.argv[1], sys.argv[2]
+    import torch
+    import torch.distributed as dist
+    from sejonggo_amd.distributed import init_from_env, tuple_dtype, gather_tuples, shard_games, broadcast_net, net_tensors
+    rank, world, dev = init_from_env(backend)
+    dt = tuple_dtype(9)
+    n = 3 + 4 * rank          # ragged: rank 0 has 3 tuples, rank 1 has 7
+    t = np.zeros(n, dtype=dt)
+    t["rank"] = rank
+    t["game"] = shard_games(2 * n * world, world, rank)[:n]
+    t["move_n"] = np.arange(n)
+    t["z"] = 1.0 - 2.0 * rank
+    t["pi"] = (np.arange(82, dtype=np.float32) + rank)[None, :]
+    t["state"] = (np.arange(dt["state"].shape[0], dtype=np.uint32) * (rank + 1))[None, :]
+    out = gather_tuples(t)
+    empty = gather_tuples(t[:0] if rank == world - 1 else t[:1])   # one rank contributes nothing
+    # weights: every rank starts from different values; after the broadcast all hold rank 0's
+    from sejonggo_amd.net import PolicyValueNet
+    torch.manual_seed(100 + rank)
+    net = PolicyValueNet(5, 1, 8, name="r%d" % rank)
+    if backend == "nccl":
+        net = net.cuda()
+    before = float(net.p_fc.weight.double().sum().item())
+    info = broadcast_net(net)
+    after = float(net.p_fc.weight.double().sum().item())
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), before=before, after=after, identical=info["identical"],
+             checksum=np.int64(info["checksum"]), nbytes=info["bytes"], n_tensors=len(net_tensors(net)),
+             out=(np.frombuffer(out.tobytes(), dtype=np.uint8) if out is not None else np.zeros(0, np.uint8)),
+             n_out=(-1 if out is None else len(out)), n_empty=(-1 if empty is None else len(empty)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

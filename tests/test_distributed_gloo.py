@@ -1,64 +1,72 @@
-"""world_size-2 gloo test of the only collective on the path: the variable-length gather of (s, pi, z)
-tuples to rank 0 (sejonggo_amd/distributed.py), plus the static game sharding."""
+"""The N > 1 path on CPU (gloo): static game sharding, the variable-length gather of (s, pi, z) tuples to rank 0 and
+the weight broadcast from rank 0 (sejonggo_amd/distributed.py), started through the launcher bench.py --gpus N uses."""
 import os
-import socket
+import sys
 
 import numpy as np
-import torch.multiprocessing as mp
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+def _launch(world, tmp_path, backend="gloo"):
+    from sejonggo_amd.distributed import launch_ranks
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+    rc = launch_ranks([os.path.join(HERE, "dist_worker.py"), backend, str(tmp_path)], world, env=env, timeout=300)
+    assert rc == 0
+    return [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
 
 
-def _worker(rank, world, port, q):
-    import torch.distributed as dist
-    from sejonggo_amd.distributed import tuple_dtype, gather_tuples, shard_games
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+def _check(res, world):
+    from sejonggo_amd.distributed import tuple_dtype
     dt = tuple_dtype(9)
-    n = 3 + 4 * rank          # ragged: rank 0 has 3 tuples, rank 1 has 7
-    t = np.zeros(n, dtype=dt)
-    t["rank"] = rank
-    t["game"] = shard_games(2 * n, world, rank)[:n]
-    t["move_n"] = np.arange(n)
-    t["z"] = 1.0 - 2.0 * rank
-    t["pi"] = (np.arange(82, dtype=np.float32) + rank)[None, :]
-    t["state"] = (np.arange(dt["state"].shape[0], dtype=np.uint32) * (rank + 1))[None, :]
-    out = gather_tuples(t)
-    empty = gather_tuples(t[:0] if rank == 1 else t[:1])   # one rank contributes nothing
-    if rank == 0:
-        q.put((out.tobytes(), len(out), len(empty)))
-    else:
-        assert out is None and empty is None
-    dist.barrier()
-    dist.destroy_process_group()
+    r0 = res[0]
+    out = np.frombuffer(r0["out"].tobytes(), dtype=dt)
+    sizes = [3 + 4 * r for r in range(world)]
+    assert int(r0["n_out"]) == sum(sizes) == len(out)
+    assert int(r0["n_empty"]) == world - 1 if world > 1 else int(r0["n_empty"]) == 0
+    assert list(out["rank"]) == sum(([r] * n for r, n in enumerate(sizes)), [])
+    o = 0
+    for r, n in enumerate(sizes):
+        part = out[o:o + n]
+        assert list(part["game"]) == [r + world * i for i in range(n)]          # game g -> rank g mod world
+        assert (part["z"] == 1.0 - 2.0 * r).all()
+        assert (part["pi"][-1] == np.arange(82, dtype=np.float32) + r).all()
+        assert (part["state"][0] == np.arange(dt["state"].shape[0], dtype=np.uint32) * (r + 1)).all()
+        o += n
+    for r in range(1, world):
+        assert int(res[r]["n_out"]) == -1 and int(res[r]["n_empty"]) == -1      # only rank 0 receives
+    # weights: different before, rank 0's after, checksums equal everywhere
+    assert len({float(x["before"]) for x in res}) == world
+    assert all(float(x["after"]) == float(res[0]["before"]) for x in res)
+    assert all(bool(x["identical"]) for x in res) and len({int(x["checksum"]) for x in res}) == 1
+    assert int(r0["n_tensors"]) > 10 and int(r0["nbytes"]) > 0
 
 
-def test_gather_tuples_world2():
-    from sejonggo_amd.distributed import tuple_dtype, shard_games
+def test_shard_games():
+    from sejonggo_amd.distributed import shard_games
     assert shard_games(10, 4, 1) == [1, 5, 9]
     assert sorted(sum((shard_games(8192, 8, r) for r in range(8)), [])) == list(range(8192))
-    ctx = mp.get_context("spawn")
-    q = ctx.SimpleQueue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    raw, n, n_empty = q.get()
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
-    dt = tuple_dtype(9)
-    out = np.frombuffer(raw, dtype=dt)
-    assert n == 10 and n_empty == 1
-    assert list(out["rank"]) == [0] * 3 + [1] * 7
-    assert list(out["game"][:3]) == [0, 2, 4] and list(out["game"][3:6]) == [1, 3, 5]
-    assert (out["z"][:3] == 1).all() and (out["z"][3:] == -1).all()
-    assert (out["pi"][5] == np.arange(82, dtype=np.float32) + 1).all()
-    assert (out["state"][9] == np.arange(dt["state"].shape[0], dtype=np.uint32) * 2).all()
+
+
+def test_gather_and_broadcast_world2(tmp_path):
+    _check(_launch(2, tmp_path), 2)
+
+
+def test_gather_and_broadcast_world1_runs_the_collectives(tmp_path):
+    """A one-rank process group still goes through all_gather / gather / broadcast (no early return)."""
+    _check(_launch(1, tmp_path), 1)
+
+
+def test_launcher_reports_a_failing_rank(tmp_path):
+    from sejonggo_amd.distributed import launch_ranks
+    script = os.path.join(str(tmp_path), "boom.py")
+    open(script, "w").write("import os, sys, time\nif os.environ['RANK'] == '1':\n    sys.exit(3)\ntime.sleep(30)\n")
+    assert launch_ranks([script], 2, timeout=60) == 3
+
+
+@pytest.mark.gpu
+def test_rccl_one_rank_on_the_device(tmp_path):
+    """backend nccl (= RCCL) with world_size 1 on the real GPU: the same all_gather / gather / broadcast calls bench.py
+    issues at N > 1, on CUDA tensors."""
+    _check(_launch(1, tmp_path, backend="nccl"), 1)

@@ -356,8 +356,12 @@ def test_other_sizes_and_energies_equal_the_oracle(L, S, sims, E, nm):
                          symmetry="identity")
     eng.start_games(np.arange(G), noises=noises, uniforms=uni)
     games = {gd["slot"]: gd for gd in eng.run()}
+    want_evals = want_none = 0
     for s in range(G):
         g = ora.Game(S, sims, E, 3, nm, komi=6.5, uniforms=uni[s], noises=noises[s:s + 1]).run(net)
+        c = g.counters()
+        want_evals += c["n_predict"]
+        want_none += c["none_events"]
         assert g.n_moves == len(games[s]["moves"]), s
         for i, mv in enumerate(games[s]["moves"]):
             m = g.move(i)
@@ -367,7 +371,8 @@ def test_other_sizes_and_energies_equal_the_oracle(L, S, sims, E, nm):
         assert ta.tobytes() == tb.tobytes(), s
         r = g.result()
         assert games[s]["black_points"] == r["black"] and games[s]["white_points"] == r["white"]
-    assert eng.status.total_evals == sum(1 + (sims // E) * E for _ in range(G)) * nm or eng.status.none_events > 0 or True
+    # network evaluations consumed and "No best leaf" events: the oracle's own counters, summed over the games
+    assert eng.status.total_evals == want_evals and eng.status.none_events == want_none
     eng.close()
 
 
