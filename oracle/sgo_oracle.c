@@ -580,7 +580,8 @@ OraGame *ora_game_new(int S, double komi, int sims, int energy, int stop_explora
     return g;
 }
 void ora_game_set_halt(OraGame *g, int move_n) { g->halt_at = move_n; }
-void ora_game_set_resign(OraGame *g, int has, float thr) { g->has_resign = has; g->resign = thr; }
+/* `if resign and value <= resign` (nomodel_self_play.py:171): a threshold of 0.0 is falsy in Python = never resign */
+void ora_game_set_resign(OraGame *g, int has, float thr) { g->has_resign = has && thr != 0.0f; g->resign = thr; }
 void ora_game_set_draws(OraGame *g, const double *uniforms, int n_u, const double *noises, int n_n) {
     g->uniforms = uniforms; g->n_uniforms = n_u; g->i_uniform = 0;
     g->noises = noises; g->n_noises = n_n; g->i_noise = 0;

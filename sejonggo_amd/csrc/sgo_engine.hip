@@ -657,7 +657,7 @@ __global__ __launch_bounds__(64) void k_start(Ctx c, int n, const float *resign)
     st.n_uniform = c.max_moves;
     st.game_seq = c.gs[g].phase == PH_IDLE && c.gs[g].game_seq == 0 && c.gs[g].n_predict == 0 ? 0 : c.gs[g].game_seq + 1;
     float r = resign ? resign[k] : NAN;
-    st.has_resign = !(r != r);
+    st.has_resign = !(r != r) && r != 0.f;   // `if resign and ...` (nomodel_self_play.py:171): None and 0.0 never resign
     st.resign = st.has_resign ? r : 0.f;
     if (c.max_moves == 0) st.phase = PH_DONE;
     for (int i = lane; i < G::RW; i += 64) c.pos[gb0 * G::RW + i] = 0;

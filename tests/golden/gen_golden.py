@@ -537,6 +537,264 @@ def child_sync(size, sims, batch, net_kind, num_moves, stop_exploration, seed, o
     print("sync S=%d sims=%d batch=%d net=%s: %d moves, result %s" % (size, sims, batch, net_kind, len(moves), gd["result"]))
 
 
+
+# ----------------------------------------------------------------------------------------------
+# the reference's own unit tests as data: every call they make into the path, with its inputs and the value
+# the reference returned, recorded while the reference's test classes run (and pass) in this container
+# ----------------------------------------------------------------------------------------------
+_TYPE_CODES = {int: 0, float: 1}
+
+
+def _tcode(v):
+    import numpy as np
+    if isinstance(v, (bool, int)) and not isinstance(v, np.generic):
+        return 0
+    if isinstance(v, float) and not isinstance(v, np.generic):
+        return 1
+    if isinstance(v, np.float32):
+        return 2
+    if isinstance(v, np.float64):
+        return 3
+    if isinstance(v, np.integer):
+        return 4
+    raise TypeError(type(v))
+
+
+def ser_tree(root):
+    """Pre-order rows of a dict tree (children in dict order).  ints: depth, action, present-mask, index, count,
+    virtual_loss, has_parent, type codes of value / mean_value / p; floats: value, mean_value, p.
+    present-mask bits: 1 index, 2 count, 4 virtual_loss, 8 value, 16 mean_value, 32 p, 64 parent key, 128 subtree is None."""
+    import numpy as np
+    ints, flts = [], []
+
+    def row(node, depth, action):
+        m = 0
+        for bit, k in ((1, "index"), (2, "count"), (4, "virtual_loss"), (8, "value"), (16, "mean_value"), (32, "p"), (64, "parent")):
+            if k in node:
+                m |= bit
+        if node.get("subtree") is None:
+            m |= 128
+        ints.append([depth, action, m, node.get("index", 0), node.get("count", 0), node.get("virtual_loss", 0),
+                     1 if node.get("parent") is not None else 0,
+                     _tcode(node.get("value", 0)), _tcode(node.get("mean_value", 0)), _tcode(node.get("p", 0))])
+        flts.append([float(node.get("value", 0)), float(node.get("mean_value", 0)), float(node.get("p", 0))])
+        for a, c in (node.get("subtree") or {}).items():
+            row(c, depth + 1, int(a))
+
+    row(root, 0, -1)
+    return np.array(ints, dtype=np.int64), np.array(flts, dtype=np.float64)
+
+
+def child_units(out):
+    import io
+    import types
+    import unittest
+    import numpy as np
+    _setup_reference(9, 8, 8)
+    sys.path.insert(0, os.path.join(REF, "test"))
+    import tests as rt
+    import tree_util_tests as tt
+    calls = []
+    current = {"test": ""}
+
+    def enc(v):
+        """-> (kind, array): 0 none, 1 ndarray, 2 int, 3 list of int tuples, 4 {int: int}, 5 float"""
+        if v is None:
+            return 0, np.zeros(0, np.int8)
+        if isinstance(v, np.ndarray):
+            return 1, v
+        if isinstance(v, (bool, int, np.integer)):
+            return 2, np.array(int(v), dtype=np.int64)
+        if isinstance(v, (float, np.floating)):
+            return 5, np.array(float(v), dtype=np.float64)
+        if isinstance(v, dict):
+            return 4, np.array(sorted((int(k), int(x)) for k, x in v.items()), dtype=np.int64).reshape(-1, 2)
+        if isinstance(v, (list, tuple)):
+            return 3, np.array([tuple(int(t) for t in e) for e in v], dtype=np.int64).reshape(len(v), 2 if not len(v) else -1)
+        raise TypeError(type(v))
+
+    def record(name, fn, n_args, defaults=(), sort_out=False, out_index=None):
+        def wrapped(*a, **k):
+            args = list(a) + [k.get(d[0], d[1]) for d in defaults[len(a) - (n_args - len(defaults)):]] if len(a) < n_args else list(a)
+            ins = [enc(np.copy(x) if isinstance(x, np.ndarray) else x) for x in args]
+            res = fn(*a, **k)
+            o = res if out_index is None else res[out_index]
+            if sort_out and o is not None:
+                o = sorted(o)
+            extra = enc(res[1]) if out_index is not None else None
+            calls.append({"fn": name, "test": current["test"], "ins": ins, "out": enc(np.copy(o) if isinstance(o, np.ndarray) else o),
+                          "out2": extra})
+            return res
+        return wrapped
+
+    # play.py functions as imported into the test module
+    rt.color_board = record("color_board", rt.color_board, 2)
+    rt._get_points = record("_get_points", rt._get_points, 1)
+    rt.capture_group = record("capture_group", rt.capture_group, 3, defaults=(("group", None),))
+    rt.make_play = record("make_play", rt.make_play, 4, defaults=(("color", None),), out_index=0)
+    rt.legal_moves = record("legal_moves", rt.legal_moves, 1)
+    rt.get_liberties = record("get_liberties", rt.get_liberties, 4, defaults=(("color", None),), sort_out=True)
+    for nm in ("left_diagonal", "right_diagonal", "vertical_axis", "horizontal_axis", "rotation_90", "rotation_180", "rotation_270",
+               "reverse_left_diagonal", "reverse_right_diagonal", "reverse_vertical_axis", "reverse_horizontal_axis",
+               "reverse_rotation_90", "reverse_rotation_180", "reverse_rotation_270"):
+        setattr(rt, nm, record(nm, getattr(rt, nm), 1))
+
+    # simulate (sync MCTS) with the model's traffic recorded
+    sims = []
+    orig_sim = rt.simulate
+
+    class Tap(object):
+        def __init__(self, model, log):
+            self.model, self.log = model, log
+            self.name = getattr(model, "name", "model")
+
+        def predict_on_batch(self, X):
+            p, v = self.model.predict_on_batch(X)
+            self.log.append((np.array(X), np.array(p), np.array(v)))
+            return p, v
+
+    depth = {"n": 0}
+
+    def sim_wrapped(node, board, model, mcts_batch_size, original_player):
+        top = depth["n"] == 0
+        depth["n"] += 1
+        try:
+            if not top:
+                return orig_sim(node, board, model, mcts_batch_size, original_player)
+            ti, tf = ser_tree(node)
+            log = []
+            b_in = np.copy(board)
+            orig_sim(node, board, Tap(model, log), mcts_batch_size, original_player)
+            oi, of = ser_tree(node)
+            sims.append({"test": current["test"], "tree_in": (ti, tf), "tree_out": (oi, of), "board_in": b_in, "board_out": np.copy(board),
+                         "batch": int(mcts_batch_size), "orig": int(original_player), "log": log})
+        finally:
+            depth["n"] -= 1
+
+    rt.simulate = sim_wrapped
+    import self_play as _sp
+    _sp_sim = _sp.simulate
+    _sp.simulate = lambda *a, **k: sim_wrapped(*a, **k)      # the recursion inside self_play goes through the module global
+    orig_sim = _sp_sim
+
+    # tree_util / back_propagation unit tests
+    trees = []
+
+    def tree_call(name, fn):
+        def wrapped(*a):
+            root = a[-1] if name == "back_propagation" else a[0]
+            ti, tf = ser_tree(root)
+            extra = {}
+            if name == "back_propagation":
+                leaf, moves = a[0]
+                extra["leaf"] = ser_tree(leaf)
+                extra["moves"] = np.array(moves, dtype=np.int64)
+            if name == "get_node_by_moves":
+                extra["moves"] = np.array(a[1], dtype=np.int64)
+            try:
+                res = fn(*a)
+                err = 0
+            except Exception:
+                res, err = None, 1
+            oi, of = ser_tree(root)
+            rec = {"fn": name, "test": current["test"], "tree_in": (ti, tf), "tree_out": (oi, of), "err": err}
+            rec.update(extra)
+            if name == "find_best_leaf_virtual_loss":
+                node, mv = res
+                rec["moves_out"] = np.array(mv if mv is not None else [-99], dtype=np.int64)
+                rec["leaf_index"] = -99 if node is None else int(node.get("index", -98))
+            elif name == "get_node_by_moves" and not err:
+                rec["leaf_index"] = int(res.get("index", -98))
+            elif name == "tree_depth":
+                rec["depth"] = int(res)
+            trees.append(rec)
+            if err:
+                raise Exception("ERROR: Unable to get node: Invalid moves array")
+            return res
+        return wrapped
+
+    for nm in ("find_best_leaf_virtual_loss", "get_node_by_moves", "back_propagation", "tree_depth"):
+        setattr(tt, nm, tree_call(nm, getattr(tt, nm)))
+    rt.tree_depth = tree_call("tree_depth", rt.tree_depth)
+
+    class Result(unittest.TextTestResult):
+        def startTest(self, test):
+            current["test"] = test.id().split(".", 1)[1]
+            super().startTest(test)
+
+    suite = unittest.TestSuite()
+    for cls in (rt.TestGoMethods, rt.TestBoardMethods, rt.TestSymmetrydTestCase, rt.MCTSTestCase, tt.TreeTestCase):
+        suite.addTests(unittest.defaultTestLoader.loadTestsFromTestCase(cls))
+    stream = io.StringIO()
+    res = unittest.TextTestRunner(stream=stream, resultclass=Result, verbosity=0).run(suite)
+    assert res.wasSuccessful(), stream.getvalue()
+    data = {"n_calls": np.array(len(calls)), "n_sims": np.array(len(sims)), "n_trees": np.array(len(trees)),
+            "tests_run": np.array(res.testsRun), "size": np.array(9), "komi": np.array(5.5)}
+
+    def put(key, kv):
+        kind, arr = kv
+        data[key + "_k"] = np.array(kind, dtype=np.int8)
+        if isinstance(arr, np.ndarray) and arr.dtype in (np.int32, np.int64) and arr.size and np.abs(arr).max() < 100:
+            arr = arr.astype(np.int8)
+        data[key] = arr
+
+    # make_play is called hundreds of times (test set-up sequences): stored stacked; the other calls one by one
+    mp = [c for c in calls if c["fn"] == "make_play"]
+    calls = [c for c in calls if c["fn"] != "make_play"]
+    data["n_calls"] = np.array(len(calls))
+    data["mp_x"] = np.array([int(c["ins"][0][1]) for c in mp], dtype=np.int16)
+    data["mp_y"] = np.array([int(c["ins"][1][1]) for c in mp], dtype=np.int16)
+    data["mp_board_in"] = np.array([c["ins"][2][1][0] for c in mp], dtype=np.int8)
+    data["mp_color"] = np.array([0 if c["ins"][3][0] == 0 else int(c["ins"][3][1]) for c in mp], dtype=np.int8)
+    data["mp_board_out"] = np.array([c["out"][1][0] for c in mp], dtype=np.int8)
+    data["mp_player"] = np.array([int(c["out2"][1]) for c in mp], dtype=np.int8)
+    for i, c in enumerate(calls):
+        p = "c%03d_" % i
+        data[p + "fn"] = np.frombuffer(c["fn"].encode(), dtype=np.uint8)
+        data[p + "test"] = np.frombuffer(c["test"].encode(), dtype=np.uint8)
+        data[p + "nin"] = np.array(len(c["ins"]))
+        for j, kv in enumerate(c["ins"]):
+            put(p + "in%d" % j, kv)
+        put(p + "out", c["out"])
+        if c["out2"] is not None:
+            put(p + "out2", c["out2"])
+    for i, c in enumerate(sims):
+        p = "s%02d_" % i
+        data[p + "test"] = np.frombuffer(c["test"].encode(), dtype=np.uint8)
+        data[p + "tin_i"], data[p + "tin_f"] = c["tree_in"]
+        data[p + "tout_i"], data[p + "tout_f"] = c["tree_out"]
+        data[p + "board_in"] = c["board_in"].astype(np.int8)
+        data[p + "board_out"] = c["board_out"].astype(np.int8)
+        data[p + "batch"] = np.array(c["batch"]); data[p + "orig"] = np.array(c["orig"])
+        data[p + "n_pred"] = np.array(len(c["log"]))
+        for j, (X, pp, vv) in enumerate(c["log"]):
+            data[p + "X%d" % j] = np.asarray(X).astype(np.int8)
+            data[p + "Xdtype%d" % j] = np.frombuffer(str(np.asarray(X).dtype).encode(), dtype=np.uint8)
+            data[p + "P%d" % j] = np.asarray(pp, dtype=np.float32)
+            data[p + "V%d" % j] = np.asarray(vv, dtype=np.float32)
+    for i, c in enumerate(trees):
+        p = "t%02d_" % i
+        data[p + "fn"] = np.frombuffer(c["fn"].encode(), dtype=np.uint8)
+        data[p + "test"] = np.frombuffer(c["test"].encode(), dtype=np.uint8)
+        data[p + "tin_i"], data[p + "tin_f"] = c["tree_in"]
+        data[p + "tout_i"], data[p + "tout_f"] = c["tree_out"]
+        data[p + "err"] = np.array(c["err"])
+        for k in ("moves", "moves_out"):
+            if k in c:
+                data[p + k] = c[k]
+        for k in ("leaf_index", "depth"):
+            if k in c:
+                data[p + k] = np.array(c[k])
+        if "leaf" in c:
+            data[p + "leaf_i"], data[p + "leaf_f"] = c["leaf"]
+    np.savez_compressed(out, **data)
+    by = {}
+    for c in calls:
+        by[c["fn"]] = by.get(c["fn"], 0) + 1
+    print("units: %d reference tests passed; recorded %d rule/symmetry calls %s, %d simulate calls, %d tree calls" % (
+        res.testsRun, len(calls), by, len(sims), len(trees)))
+
+
 # ----------------------------------------------------------------------------------------------
 # parent side
 # ----------------------------------------------------------------------------------------------
@@ -550,6 +808,7 @@ ASYNC_CASES = [
     (5, 64, 16, "dummy", None, 2, 6),
     (19, 40, 8, "hash", 6, 3, 7),
     (19, 400, 8, "hash", 2, 30, 8),          # the headline search width, two plies
+    (19, 1600, 32, "hash", 3, 30, 9),        # BASELINE.json configs[4]: 1600 sims, 32-leaf rounds (conf.py:18,29), three plies
 ]
 
 
@@ -584,6 +843,8 @@ def main():
             child_sym(int(a.child[1]), a.child[2])
         elif what == "puct":
             child_puct(a.child[1])
+        elif what == "units":
+            child_units(a.child[1])
         elif what == "sync":
             s_, sims, b, net, nm, se, seed, out = a.child[1:]
             child_sync(int(s_), int(sims), int(b), net, int(nm), int(se), int(seed), out)
@@ -603,9 +864,14 @@ def main():
             run_child(["sym", s, os.path.join(HERE, "sym_S%d.npz" % s)], scratch)
     if only in (None, "puct"):
         run_child(["puct", os.path.join(HERE, "puct.npz")], scratch)
+    if only in (None, "units"):
+        run_child(["units", os.path.join(HERE, "units_S9.npz")], scratch)
     if only in (None, "sync"):
         for i, c in enumerate(SYNC_CASES):
             run_child(["sync"] + list(c) + [os.path.join(HERE, "sync_%02d.npz" % i)], scratch)
+    if only is not None and only.startswith("async_"):
+        i = int(only.split("_")[1])
+        run_child(["async"] + list(ASYNC_CASES[i]) + [os.path.join(HERE, "async_%02d.npz" % i)], scratch)
     if only in (None, "async"):
         for i, c in enumerate(ASYNC_CASES):
             run_child(["async"] + list(c) + [os.path.join(HERE, "async_%02d.npz" % i)], scratch)
