@@ -56,6 +56,9 @@ def parse():
                     help="gloo: rehearse the N>1 path on fewer GPUs than ranks (ranks share devices, CPU tensors in the collectives)")
     ap.add_argument("--plain-net", type=int, default=0, help="1: plain PyTorch module instead of the fused inference net")
     ap.add_argument("--saturated", type=int, default=1, help="also time board_advance on a chip-filling dense batch")
+    ap.add_argument("--steady-state", type=int, default=1, help="also measure run_selfplay-style operation with slot turnover")
+    ap.add_argument("--steady-moves", type=int, default=5, help="num_moves cap of the steady-state games (short, so slots turn over)")
+    ap.add_argument("--steady-generations", type=int, default=2, help="games per slot in the steady-state leg")
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--cpu-games", type=int, default=4)
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="wall-clock budget of the CPU baseline sample")
@@ -127,6 +130,46 @@ def cpu_baseline(args, size, sims, energy, n_blocks, channels, symmetry):
             "sample": "%d concurrent games, first %d engine ticks (%d net evals = %.2f positions' worth) in a %.0f s budget; "
                       "oracle C rules+tree (1 thread) + the same net on torch CPU fp32 (torch threads %d; measured CPU time / wall = "
                       "%.1f cores), %.1f s" % (ng, ticks, evals, positions, budget, torch.get_num_threads(), busy / max(dt, 1e-9), dt)}
+
+
+def steady_state(args, net, S, G, sims, E, device, resident_value):
+    """The shipped worker body (selfplay_worker.run_selfplay) on the bench's own configuration, with games capped at
+    --steady-moves plies so that every slot finishes and is restarted --steady-generations times inside the window:
+    game-result read-back, record drain, batched restarts (one H2D copy per step), and the sample files of every
+    position written by the writer threads (sample.h5 + the .npz twin, the reference's directory layout).  The clock
+    runs from the first restart batch to the last file on disk."""
+    import shutil
+    import tempfile
+    from sejonggo_amd import predicting_queue_worker as pq
+    from sejonggo_amd.conf import conf
+    from sejonggo_amd.selfplay_worker import run_selfplay
+    keep = dict(conf)
+    tmp = tempfile.mkdtemp(prefix="sgo_steady_")
+    gens, cap = args.steady_generations, args.steady_moves
+    stats = {}
+    try:
+        conf.update(SIZE=S, MCTS_SIMULATIONS=sims, ENERGY=E, GAMES_PER_GPU=G, N_GAMES=G * gens, SELF_PLAY_DIR=tmp,
+                    STOP_EXPLORATION=30, SYMMETRY_MODE=args.symmetry, RESIGNATION_PERCENT=0.10)
+        pq.set_model_factory(lambda kind: net)
+        played = run_selfplay(device, "BEST_SYM", n_games=G * gens, games_per_gpu=G, engine_kwargs={"num_moves": cap, "seed": 4321},
+                              stats=stats)
+    finally:
+        pq.set_model_factory(None)
+        pq.destroy_predicting_workers([device])
+        conf.clear()
+        conf.update(keep)
+        shutil.rmtree(tmp, ignore_errors=True)
+    value = stats["moves"] / stats["loop_s"]
+    return {"value": value, "unit": "positions/sec", "vs_resident": value / resident_value if resident_value else None,
+            "games": played, "positions": stats["moves"], "seconds": stats["loop_s"], "engine_steps": stats["steps"],
+            "num_moves_cap": cap, "generations": gens, "sample_files": stats["files"],
+            "host_seconds": {"stepping (engine + net, incl. per-step record drain)": stats["step"],
+                             "turnover on the stepping thread (results, game_data, restart batch)": stats["turnover"],
+                             "waiting for the writer threads after the last step": stats["writer_wait"]},
+            "writer_threads": int(keep.get('WRITER_THREADS', 2)),
+            "note": "games start from the empty board and are capped at %d plies, so slots turn over every %d steps -- far more "
+                    "often than full-length games would (~300 plies); the network cost per position is the same (%d evaluations)"
+                    % (cap, cap, (sims // E) * E + 1)}
 
 
 def saturated_advance(S, n=1 << 18, ply=60, iters=10):
@@ -347,8 +390,13 @@ def run_rank(args):
                 out["roofline_board_advance"]["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
             except Exception:
                 pass
+        eng.close()
+        if args.steady_state and world == 1:
+            try:
+                out["steady_state"] = steady_state(args, net, S, G, sims, E, local, out["value"])
+            except Exception as ex:
+                out["steady_state"] = {"error": repr(ex)}
         if args.saturated and world == 1:
-            eng.close()
             try:
                 out["roofline_saturated"] = saturated_advance(S)
             except Exception as ex:

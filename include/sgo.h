@@ -183,9 +183,11 @@ sgo_ctx *sgo_ctx_create(const sgo_config *cfg);
 void sgo_ctx_destroy(sgo_ctx *ctx);
 /* (Re)start game slots.  noise: [n][A] float64 Dirichlet draws (np.random.dirichlet stand-in, consumed
  * when a tree is created); uniforms: [n][n_uniforms] float64 in [0,1) consumed one per sampled move
- * (np.random.choice stand-in); resign: [n] thresholds, NaN = None.  HOST pointers. */
+ * (np.random.choice stand-in); resign: [n] thresholds, NaN or 0 = None.  HOST pointers; they are copied before the call
+ * returns.  The batch reaches the device in ONE host-to-device copy followed by one kernel, both queued on `stream`
+ * (use the stream the steps run on): no device-wide synchronisation. */
 int sgo_start_games(sgo_ctx *ctx, int n, const int32_t *slots, const double *noise, const double *uniforms,
-                    int n_uniforms, const float *resign);
+                    int n_uniforms, const float *resign, void *stream);
 /* One engine step.  Consumes the evaluations of the positions listed by the previous step
  * (d_policy [n_eval][A] float32, d_value [n_eval] float32, produced from inputs transformed by
  * symmetry sym_k; NULL on the first call), back-propagates, selects the next leaves, plays moves whose

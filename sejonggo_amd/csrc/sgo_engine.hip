@@ -97,11 +97,32 @@ struct Ctx {
     DevStatus *dstatus;
     DevStatus *hstatus;   // pinned host
     int32_t *symLut;      // [8][A]
-    int32_t *slotList;    // [G] scratch for start_games
+    uint8_t *stage;       // device staging area of sgo_start_games (one H2D copy per call)
     int last_n_eval;      // positions listed by the previous step
 };
 
+struct StageLayout {  // byte offsets into the staging area for a batch of n restarts (all 8-byte aligned)
+    size_t slots, resign, noise, uniforms, total;
+    int nu;
+};
+static inline size_t al8(size_t v) { return (v + 7) & ~(size_t)7; }
+static StageLayout stage_layout(int n, int APAD, int nu, bool has_noise) {
+    StageLayout L;
+    L.nu = nu;
+    L.slots = 0;
+    L.resign = al8(sizeof(int32_t) * (size_t)n);
+    L.noise = L.resign + al8(sizeof(float) * (size_t)n);
+    L.uniforms = L.noise + (has_noise ? sizeof(double) * (size_t)n * APAD : 0);
+    L.total = L.uniforms + sizeof(double) * (size_t)n * nu;
+    return L;
+}
+
 struct HostSide {  // not passed to kernels
+    uint8_t *stage = nullptr;                  // pinned host twin of Ctx::stage
+    size_t stage_cap = 0;
+    hipEvent_t ev_stage = nullptr;             // the H2D copy out of `stage` has completed
+    bool stage_busy = false;
+    hipStream_t last_stream = nullptr;         // stream of the last sgo_step (records are drained behind it)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // bracket board_advance inside sgo_step
     double adv_ms = 0;
     long long adv_launches = 0, adv_positions = 0;
@@ -638,13 +659,24 @@ __global__ __launch_bounds__(1024) void k_compact(Ctx c) {
 }
 
 // (re)start listed game slots: empty board in block 0, everything else free
+// Inputs come from the staging area filled by ONE host-to-device copy: slots[n], resign[n] (NaN = None), then
+// (optionally) noise[n][APAD] and uniforms[n][nu].
 template <int S>
-__global__ __launch_bounds__(64) void k_start(Ctx c, int n, const float *resign) {
+__global__ __launch_bounds__(64) void k_start(Ctx c, int n, StageLayout L, int has_noise, int has_uniforms) {
     using G = Geo<S>;
     const int k = blockIdx.x;
     if (k >= n) return;
-    const int g = c.slotList[k];
+    const int g = reinterpret_cast<const int32_t *>(c.stage + L.slots)[k];
+    const float *resign = reinterpret_cast<const float *>(c.stage + L.resign);
     const int lane = threadIdx.x;
+    if (has_noise) {
+        const double *src = reinterpret_cast<const double *>(c.stage + L.noise) + (size_t)k * c.APAD;
+        for (int i = lane; i < c.APAD; i += 64) c.noise[(size_t)g * c.APAD + i] = src[i];
+    }
+    if (has_uniforms) {
+        const double *src = reinterpret_cast<const double *>(c.stage + L.uniforms) + (size_t)k * L.nu;
+        for (int i = lane; i < L.nu; i += 64) c.uniforms[(size_t)g * c.max_moves + i] = src[i];
+    }
     const size_t gb0 = (size_t)g * c.cap;
     GameState st;
     memset(&st, 0, sizeof st);
@@ -654,9 +686,9 @@ __global__ __launch_bounds__(64) void k_start(Ctx c, int n, const float *resign)
     st.temperature = (0 == c.cfg.stop_exploration) ? 0 : 1;
     st.e_left = -1;
     st.halt_at = -1;
-    st.n_uniform = c.max_moves;
+    st.n_uniform = has_uniforms ? L.nu : 0;   // a game that samples a move without a supplied draw fails with SGO_ERR_DRAWS
     st.game_seq = c.gs[g].phase == PH_IDLE && c.gs[g].game_seq == 0 && c.gs[g].n_predict == 0 ? 0 : c.gs[g].game_seq + 1;
-    float r = resign ? resign[k] : NAN;
+    float r = resign[k];
     st.has_resign = !(r != r) && r != 0.f;   // `if resign and ...` (nomodel_self_play.py:171): None and 0.0 never resign
     st.resign = st.has_resign ? r : 0.f;
     if (c.max_moves == 0) st.phase = PH_DONE;
@@ -743,7 +775,10 @@ static int ctx_alloc(Ctx &c) {
     CK(dalloc(&c.counters, 1));
     CK(dalloc(&c.dstatus, 1));
     CK(dalloc(&c.symLut, (size_t)8 * c.A));
-    CK(dalloc(&c.slotList, c.G));
+    {
+        const StageLayout L = stage_layout(c.G, c.APAD, c.max_moves, true);
+        CK(dalloc(&c.stage, L.total));
+    }
     SGO_HIP(hipHostMalloc((void **)&c.hstatus, sizeof(DevStatus), hipHostMallocDefault));
     memset(c.hstatus, 0, sizeof(DevStatus));
     std::vector<int32_t> lut((size_t)8 * c.A);
@@ -756,7 +791,7 @@ static void ctx_free(Ctx &c) {
     void *ptrs[] = {c.gs, c.pos, c.legal, c.cP, c.cW, c.cQ, c.cN, c.cB, c.cBusy, c.bParent, c.bSlot, c.freeList,
                     c.rootP64, c.noise, c.uniforms, c.fParent, c.fSlot, c.fBlk, c.fEvalLocal, c.fEvaluated, c.fValue,
                     c.reqBlk, c.reqParent, c.reqMove, c.evalIdx, c.leafIn, c.leafMv, c.leafOut, c.recs, c.recPacked,
-                    c.recPolicy, c.counters, c.dstatus, c.symLut, c.slotList};
+                    c.recPolicy, c.counters, c.dstatus, c.symLut, c.stage};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c.hstatus) (void)hipHostFree(c.hstatus);
@@ -786,6 +821,12 @@ sgo_ctx *sgo_ctx_create(const sgo_config *cfg) {
     size_t lds = sizeof(int32_t) * ((size_t)c.cap + 2 * c.APAD + (c.cap + 31) / 32 + 4);
     if (lds > 160 * 1024) { set_error("sgo_ctx_create: blocks_per_game too large for the LDS work queue"); delete x; return nullptr; }
     if (ctx_alloc(c) != SGO_OK) { ctx_free(c); delete x; return nullptr; }
+    x->h.stage_cap = stage_layout(c.G, c.APAD, c.max_moves, true).total;
+    if (hipHostMalloc((void **)&x->h.stage, x->h.stage_cap, hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&x->h.ev_stage, hipEventDisableTiming) != hipSuccess) {
+        set_error("sgo_ctx_create: staging allocation failed");
+        ctx_free(c); delete x; return nullptr;
+    }
     if (hipEventCreate(&x->h.ev0) != hipSuccess || hipEventCreate(&x->h.ev1) != hipSuccess) {
         set_error("sgo_ctx_create: hipEventCreate failed");
         ctx_free(c); delete x; return nullptr;
@@ -798,51 +839,48 @@ void sgo_ctx_destroy(sgo_ctx *x) {
     (void)hipSetDevice(x->c.cfg.device_id);
     (void)hipDeviceSynchronize();
     ctx_free(x->c);
+    if (x->h.stage) (void)hipHostFree(x->h.stage);
+    if (x->h.ev_stage) (void)hipEventDestroy(x->h.ev_stage);
     if (x->h.ev0) (void)hipEventDestroy(x->h.ev0);
     if (x->h.ev1) (void)hipEventDestroy(x->h.ev1);
     delete x;
 }
 
 int sgo_start_games(sgo_ctx *x, int n, const int32_t *slots, const double *noise, const double *uniforms, int n_uniforms,
-                    const float *resign) {
+                    const float *resign, void *stream) {
     if (!x || n < 0 || (n && !slots)) { set_error("sgo_start_games: bad argument"); return SGO_ERR_ARG; }
     Ctx &c = x->c;
     if (n == 0) return SGO_OK;
     if (n > c.G || n_uniforms < 0) { set_error("sgo_start_games: too many slots"); return SGO_ERR_ARG; }
-    SGO_HIP(hipSetDevice(c.cfg.device_id));
-    SGO_HIP(hipDeviceSynchronize());
     for (int i = 0; i < n; i++)
         if (slots[i] < 0 || slots[i] >= c.G) { set_error("sgo_start_games: slot out of range"); return SGO_ERR_ARG; }
-    SGO_HIP(hipMemcpy(c.slotList, slots, sizeof(int32_t) * n, hipMemcpyHostToDevice));
-    const int nu = n_uniforms < c.max_moves ? n_uniforms : c.max_moves;
-    for (int i = 0; i < n; i++) {
-        if (noise) {
-            std::vector<double> row(c.APAD, 0.0);
-            memcpy(row.data(), noise + (size_t)i * c.A, sizeof(double) * c.A);
-            SGO_HIP(hipMemcpy(c.noise + (size_t)slots[i] * c.APAD, row.data(), sizeof(double) * c.APAD, hipMemcpyHostToDevice));
-        }
-        if (uniforms && nu > 0)
-            SGO_HIP(hipMemcpy(c.uniforms + (size_t)slots[i] * c.max_moves, uniforms + (size_t)i * n_uniforms, sizeof(double) * nu,
-                              hipMemcpyHostToDevice));
-    }
-    float *d_res = nullptr;
-    if (resign) {
-        SGO_HIP(hipMalloc((void **)&d_res, sizeof(float) * n));
-        SGO_HIP(hipMemcpy(d_res, resign, sizeof(float) * n, hipMemcpyHostToDevice));
-    }
-    SGO_DISPATCH(c.S, k_start<kS><<<dim3(n), dim3(64), 0, nullptr>>>(c, n, d_res));
-    SGO_HIP(hipGetLastError());
-    SGO_HIP(hipDeviceSynchronize());
-    if (d_res) (void)hipFree(d_res);
-    if (!uniforms || nu < c.max_moves) {
-        // games that sample a move without a supplied draw fail with SGO_ERR_DRAWS: record how many were given
-        std::vector<GameState> tmp(1);
+    hipStream_t st = (hipStream_t)stream;
+    SGO_HIP(hipSetDevice(c.cfg.device_id));
+    // the pinned staging area is reused: wait (host side, this one copy only) until the previous batch has left it
+    if (x->h.stage_busy) { SGO_HIP(hipEventSynchronize(x->h.ev_stage)); x->h.stage_busy = false; }
+    const int nu = uniforms ? (n_uniforms < c.max_moves ? n_uniforms : c.max_moves) : 0;
+    const StageLayout L = stage_layout(n, c.APAD, nu, noise != nullptr);
+    uint8_t *h = x->h.stage;
+    memcpy(h + L.slots, slots, sizeof(int32_t) * n);
+    float *hr = reinterpret_cast<float *>(h + L.resign);
+    for (int i = 0; i < n; i++) hr[i] = resign ? resign[i] : NAN;
+    if (noise) {
+        double *hn = reinterpret_cast<double *>(h + L.noise);
         for (int i = 0; i < n; i++) {
-            SGO_HIP(hipMemcpy(tmp.data(), c.gs + slots[i], sizeof(GameState), hipMemcpyDeviceToHost));
-            tmp[0].n_uniform = uniforms ? nu : 0;
-            SGO_HIP(hipMemcpy(c.gs + slots[i], tmp.data(), sizeof(GameState), hipMemcpyHostToDevice));
+            memcpy(hn + (size_t)i * c.APAD, noise + (size_t)i * c.A, sizeof(double) * c.A);
+            memset(hn + (size_t)i * c.APAD + c.A, 0, sizeof(double) * (c.APAD - c.A));
         }
     }
+    if (nu > 0) {
+        double *hu = reinterpret_cast<double *>(h + L.uniforms);
+        for (int i = 0; i < n; i++) memcpy(hu + (size_t)i * nu, uniforms + (size_t)i * n_uniforms, sizeof(double) * nu);
+    }
+    // one host-to-device copy, then one kernel, both on the caller's stream: ordered against the steps before and after
+    SGO_HIP(hipMemcpyAsync(c.stage, h, L.total, hipMemcpyHostToDevice, st));
+    SGO_HIP(hipEventRecord(x->h.ev_stage, st));
+    x->h.stage_busy = true;
+    SGO_DISPATCH(c.S, k_start<kS><<<dim3(n), dim3(64), 0, st>>>(c, n, L, noise != nullptr, nu > 0));
+    SGO_HIP(hipGetLastError());
     return SGO_OK;
 }
 
@@ -850,6 +888,7 @@ int sgo_step(sgo_ctx *x, const float *d_policy, const float *d_value, int sym_k,
     if (!x || !out || sym_k < 0 || sym_k > 7) { set_error("sgo_step: bad argument"); return SGO_ERR_ARG; }
     Ctx &c = x->c;
     hipStream_t st = (hipStream_t)stream;
+    x->h.last_stream = st;
     if (c.last_n_eval > 0 && (!d_policy || !d_value)) {
         set_error("sgo_step: the previous step listed positions to evaluate; policy/value are required");
         return SGO_ERR_STATE;
@@ -896,28 +935,29 @@ int sgo_collect(sgo_ctx *x, int sym_k, int layout, int dtype, void *d_nn_in, voi
 int sgo_drain_records(sgo_ctx *x, int cap, sgo_move_record *recs, uint32_t *packed, double *policy) {
     if (!x || cap < 0) { set_error("sgo_drain_records: bad argument"); return SGO_ERR_ARG; }
     Ctx &c = x->c;
-    SGO_HIP(hipDeviceSynchronize());
-    Counters h;
-    SGO_HIP(hipMemcpy(&h, c.counters, sizeof h, hipMemcpyDeviceToHost));
-    int n = h.rec_count;
+    // sgo_step has synchronised its stream before returning, so the records (and the count in the status it returned)
+    // are complete; everything here is queued behind that stream and waited for once
+    hipStream_t st = x->h.last_stream;
+    int n = c.hstatus->n_records;
     if (n > c.rec_cap) n = c.rec_cap;
     if (n > cap) { set_error("sgo_drain_records: caller buffer too small"); return SGO_ERR_ARG; }
     if (n > 0) {
-        if (recs) SGO_HIP(hipMemcpy(recs, c.recs, sizeof(sgo_move_record) * n, hipMemcpyDeviceToHost));
-        if (packed) SGO_HIP(hipMemcpy(packed, c.recPacked, sizeof(uint32_t) * (size_t)n * c.RW, hipMemcpyDeviceToHost));
-        if (policy) SGO_HIP(hipMemcpy(policy, c.recPolicy, sizeof(double) * (size_t)n * c.A, hipMemcpyDeviceToHost));
+        if (recs) SGO_HIP(hipMemcpyAsync(recs, c.recs, sizeof(sgo_move_record) * n, hipMemcpyDeviceToHost, st));
+        if (packed) SGO_HIP(hipMemcpyAsync(packed, c.recPacked, sizeof(uint32_t) * (size_t)n * c.RW, hipMemcpyDeviceToHost, st));
+        if (policy) SGO_HIP(hipMemcpyAsync(policy, c.recPolicy, sizeof(double) * (size_t)n * c.A, hipMemcpyDeviceToHost, st));
     }
-    int zero = 0;
-    SGO_HIP(hipMemcpy(&c.counters->rec_count, &zero, sizeof zero, hipMemcpyHostToDevice));
+    SGO_HIP(hipMemsetAsync(&c.counters->rec_count, 0, sizeof(int32_t), st));
+    SGO_HIP(hipStreamSynchronize(st));
+    c.hstatus->n_records = 0;
     return n;
 }
 
 int sgo_game_results(sgo_ctx *x, int n, const int32_t *slots, sgo_game_result *out) {
     if (!x || n < 0 || !out) { set_error("sgo_game_results: bad argument"); return SGO_ERR_ARG; }
     Ctx &c = x->c;
-    SGO_HIP(hipDeviceSynchronize());
     std::vector<GameState> all(c.G);
-    SGO_HIP(hipMemcpy(all.data(), c.gs, sizeof(GameState) * c.G, hipMemcpyDeviceToHost));
+    SGO_HIP(hipMemcpyAsync(all.data(), c.gs, sizeof(GameState) * c.G, hipMemcpyDeviceToHost, x->h.last_stream));
+    SGO_HIP(hipStreamSynchronize(x->h.last_stream));
     for (int i = 0; i < n; i++) {
         int g = slots ? slots[i] : i;
         if (g < 0 || g >= c.G) { set_error("sgo_game_results: slot out of range"); return SGO_ERR_ARG; }

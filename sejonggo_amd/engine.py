@@ -42,6 +42,19 @@ def unpack_positions(packed, size):
     return boards
 
 
+class MoveRecord(dict):
+    """One move_data dict of the reference (nomodel_self_play.py:187-194: board, policy, value, move, move_n, player).
+    The position is kept in its packed 768-byte form; `record['board']` expands it to the reference's int32
+    [1,S,S,17] tensor on access (a resident 19x19 board tensor is 24.5 KB -- times ~300 moves times 1 024 games in
+    flight that would be 7.5 GB of host memory for data that is written out once)."""
+    __slots__ = ("size",)
+
+    def __missing__(self, key):
+        if key == 'board':
+            return unpack_positions(self['packed'][None], self.size)
+        raise KeyError(key)
+
+
 class SelfPlayEngine(object):
     def __init__(self, net, size=None, n_games=None, sims=None, energy=None, stop_exploration=None, num_moves=None,
                  komi=None, self_play=True, dirichlet_alpha=None, dirichlet_epsilon=None, blocks_per_game=0,
@@ -126,7 +139,7 @@ class SelfPlayEngine(object):
             # `if resign and value <= resign` (nomodel_self_play.py:171): None AND 0.0 mean "never resign"
             res = np.array([np.nan if not r else r for r in resign], dtype=np.float32)
         _lib.check(self.lib.sgo_start_games(self.ctx, C.c_int(n), _lib.ptr(slots), _lib.ptr(noises), _lib.ptr(uniforms),
-                                            C.c_int(uniforms.shape[1]), _lib.ptr(res)), "sgo_start_games")
+                                            C.c_int(uniforms.shape[1]), _lib.ptr(res), _lib.stream_ptr()), "sgo_start_games")
         for i, s in enumerate(slots):
             self.records[int(s)] = []
             self.game_ids[int(s)] = None if ids is None else ids[i]
@@ -207,18 +220,16 @@ class SelfPlayEngine(object):
         self.status.n_records = 0
         if n == 0:
             return 0
-        boards = unpack_positions(packed[:n], self.S)
         order = np.lexsort((recs["move_n"][:n], recs["game"][:n]))
         for i in order:
             r = recs[i]
             a = int(r["action"])
             y = a // self.S
             x = a - self.S * y
-            self.records.setdefault(int(r["game"]), []).append({
-                'board': boards[i:i + 1].copy(), 'policy': policy[i].copy(), 'value': np.float32(r["value"]),
-                'move': (x, y), 'move_n': int(r["move_n"]), 'player': int(r["player"]),
-                'packed': packed[i].copy(), 'action': a, 'game_seq': int(r["game_seq"]),
-            })
+            rec = MoveRecord(policy=policy[i].copy(), value=np.float32(r["value"]), move=(x, y), move_n=int(r["move_n"]),
+                             player=int(r["player"]), packed=packed[i].copy(), action=a, game_seq=int(r["game_seq"]))
+            rec.size = self.S
+            self.records.setdefault(int(r["game"]), []).append(rec)
         return n
 
     def results(self, slots=None):

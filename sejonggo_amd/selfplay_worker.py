@@ -82,8 +82,14 @@ class GameScheduler(object):
 
 
 def run_selfplay(gpu_id, model_indicator="BEST_SYM", n_games=None, games_per_gpu=None, on_game=None, max_steps=None,
-                 only_game=None):
-    """The worker body, callable in-process (tests, bench) as well as from the Process subclasses."""
+                 only_game=None, engine_kwargs=None, stats=None):
+    """The worker body, callable in-process (tests, bench) as well as from the Process subclasses.
+
+    The stepping thread only steps the engine, restarts finished slots (one batched sgo_start_games per step) and
+    hands finished games to conf['WRITER_THREADS'] writer threads, which expand the packed positions and write the
+    sample files; `stats` (a dict) receives wall-clock totals per activity."""
+    import time
+    from concurrent.futures import ThreadPoolExecutor
     from .engine import SelfPlayEngine
     from .predicting_queue_worker import init_predicting_workers, get_model, put_name_request
     from .sgfsave import save_self_play_data
@@ -95,10 +101,30 @@ def run_selfplay(gpu_id, model_indicator="BEST_SYM", n_games=None, games_per_gpu
     sched = GameScheduler(conf['SELF_PLAY_DIR'], model_name, n_games, conf['RESIGNATION_PERCENT'],
                           conf['RESIGNATION_ALLOWED_ERROR'], only_game=only_game)
     sym = conf.get('SYMMETRY_MODE', 'random1') if model_indicator.endswith("_SYM") else "identity"
-    eng = SelfPlayEngine(net, size=conf['SIZE'], n_games=G, sims=conf['MCTS_SIMULATIONS'], energy=conf['ENERGY'],
-                         stop_exploration=conf['STOP_EXPLORATION'], komi=conf['KOMI'], self_play=True, symmetry=sym,
-                         device=gpu_id, seed=gpu_id, raise_on_error=False)
+    kw = dict(size=conf['SIZE'], n_games=G, sims=conf['MCTS_SIMULATIONS'], energy=conf['ENERGY'],
+              stop_exploration=conf['STOP_EXPLORATION'], komi=conf['KOMI'], self_play=True, symmetry=sym,
+              device=gpu_id, seed=gpu_id, raise_on_error=False)
+    kw.update(engine_kwargs or {})
+    eng = SelfPlayEngine(net, **kw)
     slot_game, slot_resign = {}, {}
+    t = {"step": 0.0, "turnover": 0.0, "writer_wait": 0.0, "steps": 0, "moves": 0, "games": 0, "files": 0}
+    writers = ThreadPoolExecutor(max_workers=max(1, int(conf.get('WRITER_THREADS', 2))))
+    pending = []
+
+    def write(g, gd):
+        save_self_play_data(model_name, g, gd)
+        if on_game is not None:
+            on_game(g, gd)
+        return len(gd['moves'])
+
+    def reap(block=False):
+        keep = []
+        for f in pending:
+            if block or f.done():
+                t["files"] += f.result()          # re-raises a writer's exception in the stepping thread
+            else:
+                keep.append(f)
+        pending[:] = keep
 
     def fill(slots):
         start, res, ids = [], [], []
@@ -115,15 +141,19 @@ def run_selfplay(gpu_id, model_indicator="BEST_SYM", n_games=None, games_per_gpu
 
     played = 0
     idle = 0          # finished slots that could not be refilled (no game numbers left)
+    t_loop0 = time.perf_counter()
     try:
         active = fill(range(G))
         idle = G - active
         steps = 0
         while active > 0:
+            t0 = time.perf_counter()
             st = eng.step()
             steps += 1
             if st.n_records >= G:
                 eng.drain()
+            t1 = time.perf_counter()
+            t["step"] += t1 - t0
             if st.n_done > idle or (st.error and st.error_game in slot_game):
                 eng.drain()
                 res = eng.results()
@@ -143,25 +173,39 @@ def run_selfplay(gpu_id, model_indicator="BEST_SYM", n_games=None, games_per_gpu
                     if res[s]["done"] != 1:
                         continue
                     gd = eng.game_data(s, res[s], model_name)
+                    eng.records[s] = []        # the finished game owns its move list now
                     gd['resign_model1'] = gd['resign_model2'] = slot_resign[s]
                     g = slot_game.pop(s)
                     sched.finished(gd, slot_resign.pop(s))
                     if len(gd['moves']) == 0:
                         sched.discard(g)
                     else:
-                        save_self_play_data(model_name, g, gd)
+                        pending.append(writers.submit(write, g, gd))
                         played += 1
-                        if on_game is not None:
-                            on_game(g, gd)
+                        t["moves"] += len(gd['moves'])
                     free.append(s)
                     active -= 1
                 refilled = fill(free)
                 active += refilled
                 idle += len(free) - refilled
+                reap()
+                t["turnover"] += time.perf_counter() - t1
             if max_steps is not None and steps >= max_steps:
                 break
+        t["steps"] = steps
     finally:
-        eng.close()
+        t0 = time.perf_counter()
+        try:
+            reap(block=True)
+        finally:
+            writers.shutdown(wait=True)
+            t["writer_wait"] = time.perf_counter() - t0
+            t["loop_s"] = time.perf_counter() - t_loop0   # first restart batch .. last sample file on disk
+            t["games"] = played
+            t["net_calls"], t["net_positions"] = eng.n_net_calls, eng.n_net_positions
+            if stats is not None:
+                stats.update(t)
+            eng.close()
     return played
 
 

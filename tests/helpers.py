@@ -23,7 +23,7 @@ def name_of(z, key):
     return bytes(z[key]).decode()
 
 
-ASYNC_FILES = ["async_%02d.npz" % i for i in range(8)]
+ASYNC_FILES = ["async_%02d.npz" % i for i in range(9)]   # 08 = BASELINE config 5 (19x19, 1600 sims, 32-leaf rounds)
 
 
 def dict_tree_hash(root):

@@ -121,6 +121,70 @@ def test_many_concurrent_games_equal_the_oracle(L):
     eng.close()
 
 
+def _compare_with_oracle(eng, games, slots, S, sims, E, stop, nm, uni, noises, net, komi=5.5):
+    from oracle import oracle as ora
+    by_slot = {gd["slot"]: gd for gd in games}
+    for s in slots:
+        g = ora.Game(S, sims, E, stop, nm, komi=komi, uniforms=uni[s], noises=noises[s:s + 1]).run(net)
+        gd = by_slot[s]
+        assert g.n_moves == len(gd["moves"]) == nm, s
+        for i, mv in enumerate(gd["moves"]):
+            m = g.move(i)
+            assert mv["move"][0] + S * mv["move"][1] == m["action"] or (mv["move"][1] == S and m["action"] == S * S), (s, i)
+            assert np.array_equal(mv["board"], m["board"]) and mv["policy"].tobytes() == m["policy"].tobytes(), (s, i)
+            assert mv["player"] == m["player"] and mv["value"].tobytes() == m["value"].tobytes(), (s, i)
+        ta, na, _ = eng.tree_serialize(s)
+        tb, nb, _ = g.tree_serialize()
+        assert na == nb and ta.tobytes() == tb.tobytes(), s
+        t = eng.root_table(s)
+        o = g.root_table()
+        for k in ("N", "W", "Q", "P"):
+            assert t[k].tobytes() == np.asarray(o[k]).astype(t[k].dtype).tobytes(), (s, k)
+
+
+def test_config5_search_width_equals_the_oracle(L):
+    """BASELINE config 5's workload -- 19x19, 1 600 sims per move in rounds of 32 leaves (conf.py:18,29) -- with the
+    default block pool (10 * sims + 64 = 16 064 blocks per game, k_search's > 64 KiB dynamic-LDS path): two concurrent
+    games, two plies, every move, policy target, whole tree and root table equal to the oracle's."""
+    from sejonggo_amd.engine import SelfPlayEngine
+    from sejonggo_amd.stub_nets import make_stub
+    S, sims, E, G, nm = 19, 1600, 32, 2, 2
+    net = make_stub("hash", S)
+    rng = np.random.RandomState(55)
+    noises = rng.dirichlet([0.03] * (S * S + 1), size=G)
+    uni = rng.random_sample((G, nm))
+    eng = SelfPlayEngine(net, size=S, n_games=G, sims=sims, energy=E, stop_exploration=30, num_moves=nm, komi=5.5,
+                         symmetry="identity")
+    eng.start_games(np.arange(G), noises=noises, uniforms=uni)
+    games = eng.run()
+    assert len(games) == G and eng.status.total_evals == G * nm * (1 + sims)
+    _compare_with_oracle(eng, games, range(G), S, sims, E, 30, nm, uni, noises, net)
+    eng.close()
+
+
+def test_headline_batch_shape_equals_the_oracle_on_sampled_slots(L):
+    """The bench's own shape: 1 024 concurrent 19x19 games, 400 sims per move, 8 leaves per game and round = 8 192-leaf
+    launches of board_advance and 8 192-position evaluations.  Two plies; a handful of slots spread over the batch are
+    checked move for move and tree for tree against the oracle (the rest share the kernels and the launch)."""
+    from sejonggo_amd.engine import SelfPlayEngine
+    from sejonggo_amd.stub_nets import make_stub
+    S, sims, E, G, nm = 19, 400, 8, 1024, 2
+    net = make_stub("hash", S)
+    rng = np.random.RandomState(77)
+    noises = rng.dirichlet([0.03] * (S * S + 1), size=G)
+    uni = rng.random_sample((G, nm))
+    eng = SelfPlayEngine(net, size=S, n_games=G, sims=sims, energy=E, stop_exploration=30, num_moves=nm, komi=5.5,
+                         symmetry="identity")
+    eng.start_games(np.arange(G), noises=noises, uniforms=uni)
+    games = eng.run()
+    assert len(games) == G and eng.status.total_moves == G * nm
+    assert eng.status.total_evals == G * nm * (1 + sims) and eng.status.none_events == 0
+    ms, launches, leaves = eng.advance_timing()
+    assert leaves == G * nm * sims and launches == nm * (sims // E)          # every launch carried all 8 192 leaves
+    _compare_with_oracle(eng, games, [0, 1, 63, 64, 511, 777, 1023], S, sims, E, 30, nm, uni, noises, net)
+    eng.close()
+
+
 class _SymNet(object):
     """Oracle-side wrapper: evaluates the stub through symmetry k exactly like random_symmetry_predict
     (symmetry.py:127-132), or the 8-fold average (build extension)."""
