@@ -60,7 +60,7 @@ def parse():
     ap.add_argument("--steady-moves", type=int, default=5, help="num_moves cap of the steady-state games (short, so slots turn over)")
     ap.add_argument("--steady-generations", type=int, default=2, help="games per slot in the steady-state leg")
     ap.add_argument("--cpu-baseline", type=int, default=1)
-    ap.add_argument("--cpu-games", type=int, default=4)
+    ap.add_argument("--cpu-games", type=int, default=32, help="concurrent games of the CPU baseline (the reference's N_GAME_PROCESS, conf.py:30)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="wall-clock budget of the CPU baseline sample")
     ap.add_argument("--cpu-moves", type=int, default=1)
     return ap.parse_args()
@@ -86,7 +86,9 @@ def cpu_baseline(args, size, sims, energy, n_blocks, channels, symmetry):
         net = net.to(memory_format=torch.channels_last)
     else:
         net = make_stub(args.net, size)
+    from concurrent.futures import ThreadPoolExecutor
     ng, nm = args.cpu_games, args.cpu_moves
+    pool = ThreadPoolExecutor(max_workers=cores)      # the oracle's C calls release the GIL: games spread over the cores
     rng = np.random.RandomState(0)
     games = [ora.Game(size, sims, energy, 30, nm, uniforms=rng.random_sample(nm + 1),
                       noises=rng.dirichlet([0.03] * (size * size + 1), size=1)) for _ in range(ng)]
@@ -99,7 +101,8 @@ def cpu_baseline(args, size, sims, energy, n_blocks, channels, symmetry):
     evals = 0
     ticks = 0
     while any(g.phase != ora.PH_DONE for g in games) and time.time() - t0 < budget:
-        pend = [(g, g.pending().copy()) for g in games if g.phase != ora.PH_DONE]
+        live = [g for g in games if g.phase != ora.PH_DONE]
+        pend = list(zip(live, pool.map(lambda g: g.pending().copy(), live)))
         boards = np.concatenate([b for _, b in pend])
         pol, val = None, None
         for k in ks:
@@ -115,11 +118,13 @@ def cpu_baseline(args, size, sims, energy, n_blocks, channels, symmetry):
         val = (val / len(ks)).astype(np.float32)
         evals += len(boards)
         ticks += 1
-        o = 0
+        o, jobs = 0, []
         for g, b in pend:
-            g.submit(pol[o:o + len(b)], val[o:o + len(b)])
+            jobs.append((g, pol[o:o + len(b)], val[o:o + len(b)]))
             o += len(b)
+        list(pool.map(lambda j: j[0].submit(j[1], j[2]), jobs))
     dt = time.time() - t0
+    pool.shutdown()
     c1 = os.times()
     busy = (c1.user - c0.user) + (c1.system - c0.system)
     used = max(1, int(round(busy / max(dt, 1e-9))))   # cores actually kept busy by this process during the sample
@@ -127,9 +132,15 @@ def cpu_baseline(args, size, sims, energy, n_blocks, channels, symmetry):
     # evals_per_position network evaluations, which is where the CPU time goes)
     positions = evals / float(evals_per_position)
     return {"value": positions / dt, "unit": "positions/sec", "cores": used, "kind": "port",
-            "sample": "%d concurrent games, first %d engine ticks (%d net evals = %.2f positions' worth) in a %.0f s budget; "
-                      "oracle C rules+tree (1 thread) + the same net on torch CPU fp32 (torch threads %d; measured CPU time / wall = "
-                      "%.1f cores), %.1f s" % (ng, ticks, evals, positions, budget, torch.get_num_threads(), busy / max(dt, 1e-9), dt)}
+            "sample": "the reference's topology: %d concurrent games x %d leaves in flight each (conf.py:30-31), first %d rounds "
+                      "(%d net evals = %.2f positions' worth) in a %.0f s budget; oracle C rules+tree, games spread over %d host "
+                      "threads, + the same net on torch CPU fp32 (torch threads %d; measured CPU time / wall = %.1f cores), %.1f s"
+                      % (ng, energy, ticks, evals, positions, budget, cores, torch.get_num_threads(), busy / max(dt, 1e-9), dt),
+            # the Python reference itself cannot travel to the GPU box; its own speed as measured in the build container
+            # (8-vCPU Xeon 2.1 GHz, uniform stub net = NO network cost, one game process)
+            "reference_python": {"sync_path_19x19_400sims": 0.55, "async_path_9x9_48sims_pool8": 17.5, "sync_path_9x9_48sims": 25.3,
+                                 "unit": "positions/sec", "measured": "build container, not this box; network evaluation excluded (stub)",
+                                 "source": "BASELINE.md section 2"}}
 
 
 def steady_state(args, net, S, G, sims, E, device, resident_value):
@@ -149,7 +160,8 @@ def steady_state(args, net, S, G, sims, E, device, resident_value):
     stats = {}
     try:
         conf.update(SIZE=S, MCTS_SIMULATIONS=sims, ENERGY=E, GAMES_PER_GPU=G, N_GAMES=G * gens, SELF_PLAY_DIR=tmp,
-                    STOP_EXPLORATION=30, SYMMETRY_MODE=args.symmetry, RESIGNATION_PERCENT=0.10)
+                    STOP_EXPLORATION=30, SYMMETRY_MODE=args.symmetry,
+                    RESIGNATION_PERCENT=1.0)    # never resign: every game plays its `cap` plies (a random net resigns at move 0)
         pq.set_model_factory(lambda kind: net)
         played = run_selfplay(device, "BEST_SYM", n_games=G * gens, games_per_gpu=G, engine_kwargs={"num_moves": cap, "seed": 4321},
                               stats=stats)

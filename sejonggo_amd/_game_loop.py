@@ -5,11 +5,12 @@ priors, `player` is what make_play returned (the previous mover) from move 1 on,
 the double-pass check, trees are re-rooted with stats kept."""
 import numpy as np
 
+from .conf import conf
 from .play import game_init, get_winner, index2coord, make_play, new_tree
 
 
 def play_loop(size, first, second, evaluate, choose, name_of, stop_exploration, self_play=False, num_moves=None,
-              resign_first=None, resign_second=None, first_is_model1=True):
+              resign_first=None, resign_second=None, first_is_model1=True, async_winner_rule=False):
     """first/second: the handles (model objects or indicator strings) that play black/white.
     evaluate(handle, board) -> (policy[A], value); choose(board, tree, temperature, handle) -> action index."""
     board, player = game_init(size)
@@ -52,7 +53,15 @@ def play_loop(size, first, second, evaluate, choose, name_of, stop_exploration, 
     tag = {1: "B", 0: "D", -1: "W"}
     result = "%s+R" % tag[player] if end_reason == "resign" else "%s+%s" % (tag[winner], abs(black_points - white_points))
     nameB, nameW = name_of(first), name_of(second)
-    winner_model = None if winner == 0 else (nameB if winner == 1 else nameW)
+    if winner == 0:
+        winner_model = None
+    elif async_winner_rule and conf.get('COMPAT_WINNER_MODEL', True):
+        # nomodel_self_play.py:247: `modelB_name if (winner == 1) == model1_isblack else modelW_name` -- right while model1
+        # plays black, the LOSER's name when model1 plays white (self_play.py:258 has the correct rule).  Reproduced behind
+        # conf['COMPAT_WINNER_MODEL'] because evaluate_worker.py:141 counts wins from this field.
+        winner_model = nameB if (winner == 1) == first_is_model1 else nameW
+    else:
+        winner_model = nameB if winner == 1 else nameW
     r1, r2 = (resign_first, resign_second) if first_is_model1 else (resign_second, resign_first)
     return {'moves': moves, 'modelB_name': nameB, 'modelW_name': nameW, 'winner': {1: 1, -1: 0, 0: None}[winner],
             'winner_model': winner_model, 'result': result, 'resign_model1': r1, 'resign_model2': r2,

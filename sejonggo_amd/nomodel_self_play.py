@@ -109,10 +109,11 @@ def play_game_host(model1_indicator, model2_indicator, energy, stop_exploration,
     """play_game_async (nomodel_self_play.py:142-271) with host dict trees: the general form that also covers two
     different models (evaluate_worker.py:137: best vs latest, separate tree per player).  Rules, symmetries and
     the nets run on the GPU; one game at a time -- throughput self-play uses the device engine instead."""
+    from . import play
     from ._game_loop import play_loop
     from .predicting_queue_worker import put_predict_request
-    swap = np.random.random() >= .5
-    first, second = (model2_indicator, model1_indicator) if swap else (model1_indicator, model2_indicator)
+    first, second = play.choose_first_player(model1_indicator, model2_indicator)      # one draw of `random`, play.py:301-306
+    swap = first != model1_indicator
     r_first, r_second = (resign_model2, resign_model1) if swap else (resign_model1, resign_model2)
 
     def choose(board, tree, temperature, indicator):
@@ -121,7 +122,7 @@ def play_game_host(model1_indicator, model2_indicator, energy, stop_exploration,
 
     return play_loop(conf['SIZE'], first, second, lambda ind, board: put_predict_request(ind, board, response_now=True),
                      choose, put_name_request, stop_exploration, self_play=self_play, num_moves=num_moves,
-                     resign_first=r_first, resign_second=r_second, first_is_model1=not swap)
+                     resign_first=r_first, resign_second=r_second, first_is_model1=not swap, async_winner_rule=True)
 
 
 def back_propagation(result, node):

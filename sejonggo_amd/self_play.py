@@ -73,9 +73,10 @@ def select_play(policy, board, mcts_simulations, mcts_tree, temperature, model):
 def play_game(model1, model2, mcts_simulations, stop_exploration, self_play=False, num_moves=None, resign_model1=None,
               resign_model2=None):
     """self_play.py:164-290.  Who plays black is a coin flip (choose_first_player, play.py:301-306)."""
+    from . import play
     from ._game_loop import play_loop
-    swap = (not self_play) and np.random.random() >= .5
-    first, second = (model2, model1) if swap else (model1, model2)
+    first, second = play.choose_first_player(model1, model2)     # always one draw of `random` (self_play.py:168)
+    swap = first is not model1
     r_first, r_second = (resign_model2, resign_model1) if swap else (resign_model1, resign_model2)
 
     def evaluate(model, board):

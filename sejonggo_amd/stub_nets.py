@@ -78,10 +78,12 @@ class DummyNet(_Base):
 class HashNet(_Base):
     """Board-dependent, rounding-free pseudo net."""
 
-    def __init__(self, size, name="hash_stub"):
+    def __init__(self, size, name="hash_stub", variant=0):
         _Base.__init__(self, size, name)
         self._w = _hash_weights(size)
-        self._mul = (np.arange(self.A, dtype=np.int64) * 7919 + 13)
+        if variant:                           # a second, different pseudo net (two-model evaluation games)
+            self._w = np.roll(self._w.reshape(-1), 7 * variant).reshape(self._w.shape) + variant
+        self._mul = (np.arange(self.A, dtype=np.int64) * (7919 + 2 * variant) + 13 + variant)
         self._wt = {}
 
     def predict_on_batch(self, X):
@@ -109,4 +111,6 @@ class HashNet(_Base):
 
 
 def make_stub(kind, size):
+    if kind == "hash2":
+        return HashNet(size, name="hash_stub_2", variant=1)
     return {"uniform": UniformNet, "dummy": DummyNet, "hash": HashNet}[kind](size)

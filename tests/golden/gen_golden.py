@@ -328,20 +328,30 @@ def child_async(size, sims, energy, net_kind, num_moves, stop_exploration, seed,
     import nomodel_self_play as ns
     from sejonggo_amd.stub_nets import make_stub
     S, A = size, size * size + 1
-    net = make_stub(net_kind, size)
-    counters = {"predict": 0, "root": 0}
+    # "a+b": a two-model evaluation game (evaluate_worker.py:137): BEST* requests go to net a, LATEST* to net b
+    two = "+" in net_kind
+    kinds = net_kind.split("+") if two else [net_kind, net_kind]
+    nets = {"BEST": make_stub(kinds[0], size), "LATEST": make_stub(kinds[1], size)}
+    net = nets["BEST"]
+    counters = {"predict": 0, "root": 0, "by_model": {"BEST": 0, "LATEST": 0}}
+
+    def which(indicator):
+        return "BEST" if indicator.startswith("BEST") else "LATEST"
 
     def stub_predict(indicator, board, response_now=False):
         counters["predict"] += 1
+        counters["by_model"][which(indicator)] += 1
         if response_now:
             counters["root"] += 1
-        p, v = net.predict_on_batch(np.asarray(board))
+        p, v = nets[which(indicator)].predict_on_batch(np.asarray(board))
         assert p.dtype == np.float32 and v.dtype == np.float32
         return p[0], v[0][0]
 
     for m in (pq, sw, ns):
         m.put_predict_request = stub_predict
-        m.put_name_request = lambda ind: net.name
+        m.put_name_request = lambda ind: nets[which(ind)].name
+    first_draw = 0.25 if seed % 2 == 0 else 0.75       # play.choose_first_player: random() < .5 => model1 moves first
+    play.random = lambda: first_draw
 
     class FakePool(object):
         def apply_async(self, fn, args, error_callback=None, callback=None):
@@ -410,6 +420,7 @@ def child_async(size, sims, energy, net_kind, num_moves, stop_exploration, seed,
         per_move["root_value"].append(np.float32(tree["value"]))
         per_move["action"].append(int(a))
         per_move["temperature"].append(int(temperature))
+        per_move["model"].append(0 if which(indicator) == "BEST" else 1)
         return a
 
     ns.select_play = wrapped_select
@@ -417,8 +428,11 @@ def child_async(size, sims, energy, net_kind, num_moves, stop_exploration, seed,
     import contextlib
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):
-        gd = ns.play_game_async("BEST_SYM", "BEST_SYM", energy, stop_exploration, process_id=0,
-                                self_play=True, num_moves=num_moves)
+        if two:
+            gd = ns.play_game_async("BEST_SYM", "LATEST_SYM", energy, stop_exploration, process_id=0, num_moves=num_moves)
+        else:
+            gd = ns.play_game_async("BEST_SYM", "BEST_SYM", energy, stop_exploration, process_id=0,
+                                    self_play=True, num_moves=num_moves)
     rec["none_events"] = buf.getvalue().count("No best leaf")
     moves = gd["moves"]
     data = {
@@ -442,6 +456,13 @@ def child_async(size, sims, energy, net_kind, num_moves, stop_exploration, seed,
         "last_board": _board_i8(moves[-1]["board"]) if moves else np.zeros((S, S, 17), np.int8),
         "winner": np.array(-99 if gd["winner"] is None else gd["winner"], dtype=np.int32),
         "result": np.frombuffer(gd["result"].encode(), dtype=np.uint8),
+        "two_model": np.array(1 if two else 0, dtype=np.int32),
+        "first_draw": np.array(first_draw),
+        "modelB_name": np.frombuffer(gd["modelB_name"].encode(), dtype=np.uint8),
+        "modelW_name": np.frombuffer(gd["modelW_name"].encode(), dtype=np.uint8),
+        "winner_model": np.frombuffer(("" if gd["winner_model"] is None else gd["winner_model"]).encode(), dtype=np.uint8),
+        "n_predict_best": np.array(counters["by_model"]["BEST"], dtype=np.int32),
+        "n_predict_latest": np.array(counters["by_model"]["LATEST"], dtype=np.int32),
     }
     for k, v in per_move.items():
         data["pm_" + k] = np.array(v)
@@ -809,6 +830,10 @@ ASYNC_CASES = [
     (19, 40, 8, "hash", 6, 3, 7),
     (19, 400, 8, "hash", 2, 30, 8),          # the headline search width, two plies
     (19, 1600, 32, "hash", 3, 30, 9),        # BASELINE.json configs[4]: 1600 sims, 32-leaf rounds (conf.py:18,29), three plies
+    # two-model evaluation games (evaluate_worker.py:137: BEST_SYM vs LATEST_SYM, stop_exploration = 0, one tree per player)
+    (9, 48, 8, "hash+hash2", None, 0, 10),   # model1 (BEST) moves first, whole game
+    (9, 48, 8, "hash+hash2", 30, 0, 11),     # model2 (LATEST) moves first
+    (5, 32, 8, "hash2+hash", None, 0, 13),   # tiny board: the other tree often lacks the played move
 ]
 
 

@@ -321,3 +321,28 @@ def test_selfplay_worker_sync_path_one_game_only(tmp_path):
     games = sorted(os.listdir(os.path.join(str(tmp_path), "selfplay", "model_1")))
     assert games == ["game_00002"]
     assert os.path.isfile(os.path.join(str(tmp_path), "selfplay", "model_1", "game_00002", "move_000", "sample.h5"))
+
+
+def test_promote_best_model(tmp_path):
+    """evaluator.py:50-85 bookkeeping: win files -> win rate -> the 55 % gate -> best model replaced, results cleaned."""
+    import torch
+    from sejonggo_amd import evaluator as ev, model as M
+    conf, old = _with_conf(tmp_path, SIZE=5, N_RESIDUAL_BLOCKS=1, NET_CHANNELS=8, EVALUATE_MARGIN=.55)
+    try:
+        os.makedirs(conf['MODEL_DIR']); os.makedirs(conf['EVAL_DIR'])
+        torch.manual_seed(1)
+        M.save_model(M.PolicyValueNet(5, 1, 8, name="model_1"), "best_model")
+        torch.manual_seed(2)
+        cand = M.PolicyValueNet(5, 1, 8, name="model_2")
+        M.save_model(cand, "model_2")
+        for g in range(10):
+            ev.save_eval_game("model_2", g, "model_2" if g < 5 else "model_1")       # 50 %: not enough
+        assert ev.eval_statistic() == {"model_2": 0.5}
+        assert ev.promote_best_model() is False and M.load_best_model().name == "model_1"
+        ev.save_eval_game("model_2", 10, "model_2"); ev.save_eval_game("model_2", 11, "model_2")   # 7 / 12 = 58 %
+        assert ev.promote_best_model() is True
+        best = M.load_best_model()
+        assert best.name == "model_2" and torch.equal(best.p_fc.weight, cand.p_fc.weight)
+        assert os.listdir(conf['EVAL_DIR']) == []
+    finally:
+        _restore(conf, old)

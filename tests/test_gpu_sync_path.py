@@ -156,3 +156,75 @@ def test_gtp_front_end(sync_env):
     finally:
         pq.set_model_factory(None)
         pq.destroy_predicting_workers([0])
+
+
+TWO_MODEL_FILES = ["async_09.npz", "async_10.npz", "async_11.npz"]
+
+
+@pytest.mark.parametrize("fn", TWO_MODEL_FILES)
+def test_two_model_evaluation_game_matches_reference(sync_env, fn, monkeypatch):
+    """The evaluator's game (evaluate_worker.py:137): play_game_async("BEST_SYM", "LATEST_SYM", energy, stop_exploration=0)
+    with two DIFFERENT nets, one tree per player, the mover's tree re-rooted and the other tree followed when it holds
+    the move (nomodel_self_play.py:203-218).  Fixtures recorded from the reference with either model moving first;
+    compared move for move, tree for tree (both players' trees, after every search), and in the game_data fields the
+    evaluator reads -- including winner_model, which the reference gets wrong when model1 plays white (:247)."""
+    from sejonggo_amd import nomodel_self_play as ns, play, predicting_queue_worker as pq
+    from sejonggo_amd.stub_nets import make_stub
+    from tests.helpers import dict_tree_hash, name_of
+    z = load(fn)
+    assert int(z["two_model"]) == 1
+    S = int(z["size"])
+    nm = int(z["num_moves"])
+    sync_env.update({'SIZE': S, 'MCTS_SIMULATIONS': int(z["sims"]), 'ENERGY': int(z["energy"]), 'KOMI': float(z["komi"]),
+                     'COMPAT_LATEST_SYM': False, 'COMPAT_WINNER_MODEL': True})
+    kinds = name_of(z, "net").split("+")
+    nets = {"BEST": make_stub(kinds[0], S), "LATEST": make_stub(kinds[1], S)}
+    seen = {"BEST": 0, "LATEST": 0}
+
+    class Counting(object):
+        def __init__(self, kind):
+            self.kind, self.name, self.numpy_native = kind, nets[kind].name, True
+
+        def predict_on_batch(self, X):
+            seen[self.kind] += len(X)
+            return nets[self.kind].predict_on_batch(X)
+
+    wrapped_nets = {k: Counting(k) for k in nets}
+    pq.set_model_factory(lambda kind: wrapped_nets[kind])
+    pq.init_predicting_workers([0])
+    monkeypatch.setattr(play, "random", lambda: float(z["first_draw"]))
+    trace = []
+    orig = ns.select_play
+
+    def wrapped(board, energy, tree, temperature, indicator, gpuid):
+        a = orig(board, energy, tree, temperature, indicator, gpuid)
+        trace.append((dict_tree_hash(tree)[0], 0 if indicator.startswith("BEST") else 1, temperature, tree['count']))
+        return a
+
+    monkeypatch.setattr(ns, "select_play", wrapped)
+    try:
+        gd = ns.play_game_async("BEST_SYM", "LATEST_SYM", int(z["energy"]), int(z["stop_exploration"]), 0,
+                                num_moves=None if nm < 0 else nm)
+    finally:
+        pq.set_model_factory(None)
+        pq.destroy_predicting_workers([0])
+    assert len(gd['moves']) == len(z["move_index"])
+    for i, mv in enumerate(gd['moves']):
+        a = mv['move'][0] + S * mv['move'][1] if mv['move'][1] != S else S * S
+        assert a == z["move_index"][i] and mv['player'] == z["move_player"][i], i
+        assert np.float32(mv['value']).tobytes() == z["move_value"][i].tobytes(), i
+        assert mv['policy'].tobytes() == z["move_policy"][i].tobytes(), i
+        assert np.array_equal(sha8(mv['board']), z["move_board_hash"][i]), i
+        h, model, temp, root_count = trace[i]
+        assert h == z["pm_tree_hash"][i].tobytes() and model == z["pm_model"][i], i
+        assert temp == z["pm_temperature"][i] == 0 and root_count == z["pm_root_count"][i], i
+    assert gd['result'] == name_of(z, "result")
+    assert (-99 if gd['winner'] is None else gd['winner']) == int(z["winner"])
+    assert gd['modelB_name'] == name_of(z, "modelB_name") and gd['modelW_name'] == name_of(z, "modelW_name")
+    assert (gd['winner_model'] or "") == name_of(z, "winner_model")
+    assert seen["BEST"] == int(z["n_predict_best"]) and seen["LATEST"] == int(z["n_predict_latest"])
+    # the quirk, made explicit: with model1 (BEST) on white the reference names the loser
+    model1_black = float(z["first_draw"]) < .5
+    if int(z["winner"]) in (0, 1):
+        true_winner = gd['modelB_name'] if int(z["winner"]) == 1 else gd['modelW_name']
+        assert (gd['winner_model'] == true_winner) == model1_black
