@@ -194,6 +194,14 @@ int sgo_start_games(sgo_ctx *ctx, int n, const int32_t *slots, const double *noi
  * search is complete, computes the new leaf positions, and reports what must be evaluated next.
  * Synchronises `stream` once to return `st`. */
 int sgo_step(sgo_ctx *ctx, const float *d_policy, const float *d_value, int sym_k, void *stream, sgo_status *st);
+/* sgo_step with nn_input_pack FUSED into board_advance (predicting_queue_worker.py:53-71's batch assembly): the kernel
+ * that plays a leaf's move also writes that leaf's network-input row -- fp16, NHWC with the channels zero-padded to 32
+ * ([n_eval][S][S][32], layout 2 of sgo_nn_pack_dev), transformed by symmetry next_k -- into d_nn_in, and the (at most one
+ * per game) root requests are packed by a small kernel behind it.  No sgo_collect call is needed afterwards; pass next_k
+ * as sym_k of the following step.  Falls back to separate kernels inside when the leaf list exceeds the fused form's
+ * launch shape (> 32 768 leaves). */
+int sgo_step_fused(sgo_ctx *ctx, const float *d_policy, const float *d_value, int sym_k, int next_k, void *d_nn_in,
+                   void *stream, sgo_status *st);
 /* Network input for the positions listed by the last sgo_step (same order as the results expected). */
 int sgo_collect(sgo_ctx *ctx, int sym_k, int layout, int dtype, void *d_nn_in, void *stream);
 /* Move records produced so far (HOST buffers): recs[cap], boards packed [cap][packed_words],

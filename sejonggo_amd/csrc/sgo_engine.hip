@@ -60,7 +60,7 @@ struct Counters {
 };
 
 struct DevStatus {  // written by k_compact, copied to the host once per step
-    int32_t n_eval, n_leaf, n_records, n_active, n_done, error, error_game, pad;
+    int32_t n_eval, n_leaf, n_records, n_active, n_done, error, error_game, n_root;
     unsigned long long total_moves, total_evals, none_events;
 };
 
@@ -89,6 +89,8 @@ struct Ctx {
     int32_t *reqBlk, *reqParent, *reqMove;  // [G][E]; block ids are GLOBAL (g*cap + local)
     // compacted lists
     int32_t *evalIdx, *leafIn, *leafMv, *leafOut;  // [G*E]
+    int32_t *leafRow;     // [G*E] row of each leaf in the evaluation list (fused board_advance + nn_input_pack)
+    int32_t *rootIdx, *rootRow;  // [G] block id / evaluation row of this step's root requests
     // records
     sgo_move_record *recs;
     uint32_t *recPacked;
@@ -604,32 +606,33 @@ __global__ __launch_bounds__(64) void k_search(Ctx c, const float *policy, const
 // One block.  Exclusive prefix sums of the per-game request counts -> dense evaluation list (block ids
 // in game-major order) and dense leaf list for board_advance; also folds the status words.
 __global__ __launch_bounds__(1024) void k_compact(Ctx c) {
-    __shared__ int sE[1024], sL[1024];
+    __shared__ int sE[1024], sL[1024], sR[1024];
     __shared__ int sAct[1024], sDone[1024], sErr[1024];
     const int t = threadIdx.x;
     const int per = (c.G + 1023) / 1024;
     const int g0 = t * per, g1 = min(c.G, g0 + per);
-    int ne = 0, nl = 0, act = 0, done = 0, err = 0x7fffffff;
+    int ne = 0, nl = 0, nr = 0, act = 0, done = 0, err = 0x7fffffff;
     for (int g = g0; g < g1; g++) {
         const GameState &s = c.gs[g];
         ne += s.n_req;
         if (s.req_kind == 1) nl += s.n_req;
+        else nr += s.n_req;
         if (s.phase == PH_WAIT_ROOT || s.phase == PH_SEARCH) act++;
         if (s.phase == PH_DONE) done++;
         if (s.error && err == 0x7fffffff) err = g;
     }
-    sE[t] = ne; sL[t] = nl; sAct[t] = act; sDone[t] = done; sErr[t] = err;
+    sE[t] = ne; sL[t] = nl; sR[t] = nr; sAct[t] = act; sDone[t] = done; sErr[t] = err;
     __syncthreads();
     // Hillis-Steele inclusive scan
     for (int o = 1; o < 1024; o <<= 1) {
-        int ve = (t >= o) ? sE[t - o] : 0, vl = (t >= o) ? sL[t - o] : 0;
+        int ve = (t >= o) ? sE[t - o] : 0, vl = (t >= o) ? sL[t - o] : 0, vq = (t >= o) ? sR[t - o] : 0;
         int va = (t >= o) ? sAct[t - o] : 0, vd = (t >= o) ? sDone[t - o] : 0;
         int vr = (t >= o) ? sErr[t - o] : 0x7fffffff;
         __syncthreads();
-        sE[t] += ve; sL[t] += vl; sAct[t] += va; sDone[t] += vd; sErr[t] = min(sErr[t], vr);
+        sE[t] += ve; sL[t] += vl; sR[t] += vq; sAct[t] += va; sDone[t] += vd; sErr[t] = min(sErr[t], vr);
         __syncthreads();
     }
-    int be = sE[t] - ne, bl = sL[t] - nl;
+    int be = sE[t] - ne, bl = sL[t] - nl, br = sR[t] - nr;
     for (int g = g0; g < g1; g++) {
         GameState &s = c.gs[g];
         s.eval_base = be;
@@ -639,10 +642,15 @@ __global__ __launch_bounds__(1024) void k_compact(Ctx c) {
                 c.leafIn[bl + j] = c.reqParent[(size_t)g * c.E + j];
                 c.leafMv[bl + j] = c.reqMove[(size_t)g * c.E + j];
                 c.leafOut[bl + j] = c.reqBlk[(size_t)g * c.E + j];
+                c.leafRow[bl + j] = be + j;
+            } else {
+                c.rootIdx[br + j] = c.reqBlk[(size_t)g * c.E + j];
+                c.rootRow[br + j] = be + j;
             }
         }
         be += s.n_req;
         if (s.req_kind == 1) bl += s.n_req;
+        else br += s.n_req;
     }
     if (t == 1023) {
         DevStatus d;
@@ -651,7 +659,7 @@ __global__ __launch_bounds__(1024) void k_compact(Ctx c) {
         int eg = sErr[1023];
         d.error_game = (eg == 0x7fffffff) ? -1 : eg;
         d.error = (eg == 0x7fffffff) ? 0 : c.gs[eg].error;
-        d.pad = 0;
+        d.n_root = sR[1023];
         d.total_moves = c.counters->total_moves; d.total_evals = c.counters->total_evals;
         d.none_events = c.counters->none_events;
         *c.dstatus = d;
@@ -769,6 +777,9 @@ static int ctx_alloc(Ctx &c) {
     CK(dalloc(&c.leafIn, nr));
     CK(dalloc(&c.leafMv, nr));
     CK(dalloc(&c.leafOut, nr));
+    CK(dalloc(&c.leafRow, nr));
+    CK(dalloc(&c.rootIdx, nr));
+    CK(dalloc(&c.rootRow, nr));
     CK(dalloc(&c.recs, (size_t)c.rec_cap));
     CK(dalloc(&c.recPacked, (size_t)c.rec_cap * c.RW));
     CK(dalloc(&c.recPolicy, (size_t)c.rec_cap * c.A));
@@ -790,7 +801,7 @@ static int ctx_alloc(Ctx &c) {
 static void ctx_free(Ctx &c) {
     void *ptrs[] = {c.gs, c.pos, c.legal, c.cP, c.cW, c.cQ, c.cN, c.cB, c.cBusy, c.bParent, c.bSlot, c.freeList,
                     c.rootP64, c.noise, c.uniforms, c.fParent, c.fSlot, c.fBlk, c.fEvalLocal, c.fEvaluated, c.fValue,
-                    c.reqBlk, c.reqParent, c.reqMove, c.evalIdx, c.leafIn, c.leafMv, c.leafOut, c.recs, c.recPacked,
+                    c.reqBlk, c.reqParent, c.reqMove, c.evalIdx, c.leafIn, c.leafMv, c.leafOut, c.leafRow, c.rootIdx, c.rootRow, c.recs, c.recPacked,
                     c.recPolicy, c.counters, c.dstatus, c.symLut, c.stage};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -884,7 +895,21 @@ int sgo_start_games(sgo_ctx *x, int n, const int32_t *slots, const double *noise
     return SGO_OK;
 }
 
+static int step_impl(sgo_ctx *x, const float *d_policy, const float *d_value, int sym_k, int next_k, void *d_nn_in, void *stream,
+                     sgo_status *out);
+
 int sgo_step(sgo_ctx *x, const float *d_policy, const float *d_value, int sym_k, void *stream, sgo_status *out) {
+    return step_impl(x, d_policy, d_value, sym_k, 0, nullptr, stream, out);
+}
+
+int sgo_step_fused(sgo_ctx *x, const float *d_policy, const float *d_value, int sym_k, int next_k, void *d_nn_in, void *stream,
+                   sgo_status *out) {
+    if (!d_nn_in || next_k < 0 || next_k > 7) { set_error("sgo_step_fused: bad argument"); return SGO_ERR_ARG; }
+    return step_impl(x, d_policy, d_value, sym_k, next_k, d_nn_in, stream, out);
+}
+
+static int step_impl(sgo_ctx *x, const float *d_policy, const float *d_value, int sym_k, int next_k, void *d_nn_in, void *stream,
+                     sgo_status *out) {
     if (!x || !out || sym_k < 0 || sym_k > 7) { set_error("sgo_step: bad argument"); return SGO_ERR_ARG; }
     Ctx &c = x->c;
     hipStream_t st = (hipStream_t)stream;
@@ -906,9 +931,21 @@ int sgo_step(sgo_ctx *x, const float *d_policy, const float *d_value, int sym_k,
     SGO_HIP(hipEventRecord(x->h.ev0, st));
     const int max_leaf = c.G * c.E;
     // parents (leafIn) and freshly allocated blocks (leafOut) are disjoint block sets => split form
-    CK(launch_advance_split(c.S, max_leaf, &c.dstatus->n_leaf, c.pos, c.leafIn, c.leafMv, nullptr, c.pos, c.leafOut, c.legal,
-                            c.leafOut, nullptr, st));
+    const bool fused = d_nn_in && advance_rows_nn_fits(max_leaf);
+    if (fused) {
+        // one kernel: parent record -> child record + legal bits + the child's fp16 NHWC-32 network-input row
+        CK(launch_advance_rows_nn(c.S, max_leaf, &c.dstatus->n_leaf, c.pos, c.leafIn, c.leafMv, c.pos, c.leafOut, c.legal,
+                                  c.leafOut, c.leafRow, next_k, d_nn_in, st));
+    } else {
+        CK(launch_advance_split(c.S, max_leaf, &c.dstatus->n_leaf, c.pos, c.leafIn, c.leafMv, nullptr, c.pos, c.leafOut, c.legal,
+                                c.leafOut, nullptr, st));
+    }
     SGO_HIP(hipEventRecord(x->h.ev1, st));
+    if (d_nn_in) {
+        // root requests (at most one per game) keep the stand-alone pack; without the fused form so do the leaves
+        CK(launch_nn_pack_rows(c.S, c.G, &c.dstatus->n_root, c.pos, c.rootIdx, c.rootRow, next_k, d_nn_in, st));
+        if (!fused) CK(launch_nn_pack_rows(c.S, max_leaf, &c.dstatus->n_leaf, c.pos, c.leafOut, c.leafRow, next_k, d_nn_in, st));
+    }
     SGO_HIP(hipMemcpyAsync(c.hstatus, c.dstatus, sizeof(DevStatus), hipMemcpyDeviceToHost, st));
     SGO_HIP(hipStreamSynchronize(st));
     const DevStatus &d = *c.hstatus;

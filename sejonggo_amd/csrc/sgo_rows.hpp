@@ -206,4 +206,59 @@ SGO_DEV int advance_record_rows(const uint32_t *in, uint32_t *out, int a, bool s
 }
 
 }  // namespace rows
+
+// What the fused board_advance + nn_input_pack kernel keeps from the ply: word `lane` of the child's planes 0 / 1 (valid in
+// lanes 0..NW-1 of the half) and who is to move in the child.
+template <int S>
+struct Board_rows_result {
+    uint32_t w0, w1;
+    bool child_white;
+};
+
+// advance_record_rows of a LEGAL move (the engine's leaves: the move comes from the legal set), keeping the new pair in
+// registers.  out / legal_out may be null for an idle half (nothing is written; the wave stays converged).
+template <int S>
+SGO_DEV void rows_advance_keep(const uint32_t *in, uint32_t *out, int a, uint32_t *legal_out, int half, int y,
+                               Board_rows_result<S> &res) {
+    using G = Geo<S>;
+    rows::Board<S> bd;
+    bd.half = half;
+    bd.y = y;
+    bd.M = (y < S) ? G::ROWMASK : 0u;
+    const bool mover_white = (in[G::META_WORD] & G::META_BIT) != 0;
+    const uint32_t black = rows::load_row<S>(in, y), white = rows::load_row<S>(in + G::NW, y);
+    uint32_t own = mover_white ? white : black, opp = mover_white ? black : white;
+    const uint32_t before_opp = opp;
+    (void)bd.advance(own, opp, a);
+    const uint32_t lg = bd.legal(opp, own, before_opp);
+    const uint32_t nb = mover_white ? opp : own, nw = mover_white ? own : opp;
+    uint32_t w0 = rows::gather_word<S>(nb, half, y), w1 = rows::gather_word<S>(nw, half, y), wl = rows::gather_word<S>(lg, half, y);
+    if (y == G::META_WORD && !mover_white) w0 |= G::META_BIT;   // black moved => white to play
+    if (y == (G::N >> 5)) wl |= 1u << (G::N & 31);              // pass is always legal
+    res.w0 = w0;
+    res.w1 = w1;
+    res.child_white = !mover_white;
+    if (!out) return;
+    if (y < G::NW) {
+        out[y] = w0;
+        out[G::NW + y] = w1;
+        legal_out[y] = wl;
+    }
+    if constexpr (G::NW % 4 == 0) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 *s = reinterpret_cast<const u32x4 *>(in);
+        u32x4 *d = reinterpret_cast<u32x4 *>(out + 2 * G::NW);
+#pragma unroll
+        for (int c0 = 0; c0 < 14 * G::NW / 4; c0 += 32) {
+            const int c = c0 + y;
+            if (c < 14 * G::NW / 4) d[c] = s[c];
+        }
+    } else {
+#pragma unroll
+        for (int c0 = 0; c0 < 14 * G::NW; c0 += 32) {
+            const int c = c0 + y;
+            if (c < 14 * G::NW) out[2 * G::NW + c] = in[c];
+        }
+    }
+}
 }  // namespace sgo

@@ -244,6 +244,63 @@ __global__ __launch_bounds__(64) void k_board_advance_rows(int n, const int *n_d
     if (status && y == 0) status[i] = st ? st : mover;
 }
 
+// board_advance FUSED with nn_input_pack for the engine's leaf list: the half-wave that plays the move also emits the
+// child's network-input row (fp16, NHWC with the channels zero-padded to 32, symmetry k applied on the gather side), so the
+// child record is not read again by a pack kernel.  The sixteen plane bits of a point come from registers for the new pair
+// (plane words held by lanes 0..NW-1 of the half, fetched with ds_bpermute) and from the parent record for the history
+// (parent planes 0..13 = child planes 2..15; those lines were just loaded by the history move of the same half-wave).
+// Output mapping: four lanes write the four 16-byte quarters of one point, so a half-wave store instruction covers eight
+// consecutive points = 512 contiguous bytes.  nn_row[i] = row of leaf i in the evaluation list.
+template <int S>
+__global__ __launch_bounds__(64) void k_board_advance_rows_nn(int n, const int *n_dev, const uint32_t *in, const int32_t *in_idx,
+                                                              const int32_t *moves, uint32_t *out, const int32_t *out_idx,
+                                                              uint32_t *legal, const int32_t *legal_idx, const int32_t *nn_row,
+                                                              int k, _Float16 *nn_out) {
+    using G = Geo<S>;
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    if (n_dev) n = *n_dev;
+    const int half = threadIdx.x >> 5, y = threadIdx.x & 31;
+    const int i0 = blockIdx.x * 2;
+    if (i0 >= n) return;
+    const bool live = i0 + half < n;                 // the second half of the last wave idles but keeps the wave converged
+    const int i = live ? i0 + half : i0;
+    const uint32_t *src = in + (size_t)in_idx[i] * G::RW;
+    uint32_t *dst = out + (size_t)out_idx[i] * G::RW;
+    uint32_t *lg = legal + (size_t)legal_idx[i] * G::NW;
+    // ---- the ply itself (same code path as k_board_advance_rows)
+    Board_rows_result<S> r;
+    rows_advance_keep<S>(src, live ? dst : nullptr, moves[i], live ? lg : nullptr, half, y, r);
+    // ---- network input row of the child
+    const int flip = r.child_white ? 1 : 0;          // planes relative to the side to move: relative c = absolute c ^ flip
+    _Float16 *orow = nn_out + (size_t)nn_row[i] * G::N * 32;
+    const int q = y & 3;
+#pragma unroll 1
+    for (int p0 = 0; p0 < G::N; p0 += 8) {
+        const int pt = p0 + (y >> 2);
+        const int pp = pt < G::N ? pt : G::N - 1;
+        const int pi = pp / S, pj = pp - pi * S;
+        int si, sj;
+        sym_src(S, k, pi, pj, si, sj);
+        const int sp = si * S + sj, wi = sp >> 5, sh = sp & 31;
+        // the child's planes 0 / 1 live in lanes 0..NW-1 of this half (word index = lane)
+        const uint32_t nb = (uint32_t)__shfl((int)r.w0, half * 32 + wi, 64), nw = (uint32_t)__shfl((int)r.w1, half * 32 + wi, 64);
+        h8 v;
+#pragma unroll
+        for (int c = 0; c < 8; c++) v[c] = (_Float16)0.0f;
+        if (q < 2) {
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const int a = (q * 8 + c) ^ flip;    // absolute plane of relative channel q*8 + c
+                const uint32_t word = (a == 0) ? nb : (a == 1) ? nw : src[(a - 2) * G::NW + wi];
+                v[c] = (_Float16)(float)((word >> sh) & 1u);
+            }
+        } else if (q == 2) {
+            v[0] = (_Float16)(flip ? -1.0f : 1.0f);
+        }
+        if (live && pt < G::N) *reinterpret_cast<h8 *>(orow + (size_t)pt * 32 + q * 8) = v;
+    }
+}
+
 template <int S>
 __global__ __launch_bounds__(256) void k_legal(int n, const uint32_t *packed, const int32_t *idx, uint32_t *legal) {
     using G = Geo<S>;
@@ -535,6 +592,56 @@ int launch_advance_split(int S, int n_max, const int *d_n, const uint32_t *d_in,
         }
         }
     });
+    SGO_HIP(hipGetLastError());
+    return SGO_OK;
+}
+
+// nn_input_pack for a device-counted list of (record, output row) pairs -- the root evaluations of a fused engine step,
+// whose leaves were packed by k_board_advance_rows_nn.  fp16 NHWC-32 only.  Four lanes per point, like the fused kernel.
+template <int S>
+__global__ __launch_bounds__(256) void k_nn_pack_rows(const int *n_dev, const uint32_t *packed, const int32_t *idx, const int32_t *rows_,
+                                                      int k, _Float16 *out) {
+    using G = Geo<S>;
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    const int n = *n_dev;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long)n * G::N * 4) return;
+    const int e = (int)(gid / (G::N * 4)), rem = (int)(gid - (long)e * G::N * 4), pt = rem >> 2, q = rem & 3;
+    const int pi = pt / S, pj = pt - pi * S;
+    int si, sj;
+    sym_src(S, k, pi, pj, si, sj);
+    const int sp = si * S + sj;
+    const uint32_t *rec = packed + (size_t)idx[e] * G::RW;
+    const int flip = white_to_play<S>(rec) ? 1 : 0;
+    h8 v;
+#pragma unroll
+    for (int c = 0; c < 8; c++) v[c] = (_Float16)0.0f;
+    if (q < 2) {
+#pragma unroll
+        for (int c = 0; c < 8; c++) v[c] = (_Float16)(float)((rec[((q * 8 + c) ^ flip) * G::NW + (sp >> 5)] >> (sp & 31)) & 1u);
+    } else if (q == 2) {
+        v[0] = (_Float16)(flip ? -1.0f : 1.0f);
+    }
+    *reinterpret_cast<h8 *>(out + ((size_t)rows_[e] * G::N + pt) * 32 + q * 8) = v;
+}
+
+bool advance_rows_nn_fits(int n_max) { return n_max <= ROWS_MAX_LEAVES; }
+
+int launch_advance_rows_nn(int S, int n_max, const int *d_n, const uint32_t *d_in, const int32_t *d_in_idx, const int32_t *d_moves,
+                           uint32_t *d_out, const int32_t *d_out_idx, uint32_t *d_legal, const int32_t *d_legal_idx,
+                           const int32_t *d_nn_row, int k, void *d_nn_out, hipStream_t st) {
+    if (n_max <= 0) return SGO_OK;
+    SGO_DISPATCH(S, (k_board_advance_rows_nn<kS><<<dim3(cdiv(n_max, 2)), dim3(64), 0, st>>>(
+                        n_max, d_n, d_in, d_in_idx, d_moves, d_out, d_out_idx, d_legal, d_legal_idx, d_nn_row, k, (_Float16 *)d_nn_out)));
+    SGO_HIP(hipGetLastError());
+    return SGO_OK;
+}
+
+int launch_nn_pack_rows(int S, int n_max, const int *d_n, const uint32_t *d_packed, const int32_t *d_idx, const int32_t *d_rows, int k,
+                        void *d_out, hipStream_t st) {
+    if (n_max <= 0) return SGO_OK;
+    SGO_DISPATCH(S, (k_nn_pack_rows<kS><<<dim3(cdiv((long)n_max * kS * kS * 4, 256)), dim3(256), 0, st>>>(
+                        d_n, d_packed, d_idx, d_rows, k, (_Float16 *)d_out)));
     SGO_HIP(hipGetLastError());
     return SGO_OK;
 }

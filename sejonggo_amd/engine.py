@@ -58,7 +58,7 @@ class MoveRecord(dict):
 class SelfPlayEngine(object):
     def __init__(self, net, size=None, n_games=None, sims=None, energy=None, stop_exploration=None, num_moves=None,
                  komi=None, self_play=True, dirichlet_alpha=None, dirichlet_epsilon=None, blocks_per_game=0,
-                 device=0, symmetry="random1", layout="nhwc", dtype="fp16", seed=0, raise_on_error=True):
+                 device=0, symmetry="random1", layout="nhwc", dtype="fp16", seed=0, raise_on_error=True, fused_pack=True):
         import torch
         self.torch = torch
         self.lib = _lib.require_gpu()
@@ -106,6 +106,10 @@ class SelfPlayEngine(object):
         self.n_net_calls = 0
         self.n_net_positions = 0
         self._primed = False
+        # nn_input_pack fused into board_advance (sgo_step_fused): the step that lists positions also writes their network
+        # input, for the fused net's layout (fp16 NHWC-32) and one symmetry per batch
+        self.fused_pack = bool(fused_pack) and self.layout == 2 and self.dtype == 0 and symmetry != "avg8"
+        self._k_packed = 0             # symmetry the rows waiting in nn_in were packed with
         self.raise_on_error = raise_on_error   # False: a failing slot (e.g. block pool exhausted) is left to the caller
 
     def close(self):
@@ -152,10 +156,18 @@ class SelfPlayEngine(object):
             self._luts = [torch.from_numpy(sym_lut(self.S, kk).astype(np.int64)).to(self.device) for kk in range(8)]
         return self._luts[k]
 
-    def _forward(self, n, k):
+    def _draw_k(self):
+        if self.symmetry == "identity":
+            return 0
+        if self.symmetry == "random1":
+            return self.pyrng.randrange(7)  # choice(SYMMETRIES), symmetry.py:128
+        return int(self.symmetry)
+
+    def _forward(self, n, k, packed=False):
         torch = self.torch
-        _lib.check(self.lib.sgo_collect(self.ctx, C.c_int(k), C.c_int(self.layout), C.c_int(self.dtype),
-                                        _lib.ptr(self.nn_in), _lib.stream_ptr()), "sgo_collect")
+        if not packed:
+            _lib.check(self.lib.sgo_collect(self.ctx, C.c_int(k), C.c_int(self.layout), C.c_int(self.dtype),
+                                            _lib.ptr(self.nn_in), _lib.stream_ptr()), "sgo_collect")
         x = self.nn_in[:n]
         if self.layout == 1:
             x = x.permute(0, 2, 3, 1)  # present the reference's NHWC view
@@ -180,13 +192,13 @@ class SelfPlayEngine(object):
                 pol = (pol / 8.0).contiguous()
                 val = (val / 8.0).contiguous()
                 k_used = 0
+            elif self.fused_pack:
+                k_used = self._k_packed          # the rows were written by the previous sgo_step_fused
+                pol, val = self._forward(n, k_used, packed=True)
+                pol = pol.contiguous()
+                val = val.contiguous()
             else:
-                if self.symmetry == "identity":
-                    k_used = 0
-                elif self.symmetry == "random1":
-                    k_used = self.pyrng.randrange(7)  # choice(SYMMETRIES), symmetry.py:128
-                else:
-                    k_used = int(self.symmetry)
+                k_used = self._draw_k()
                 pol, val = self._forward(n, k_used)
                 pol = pol.contiguous()
                 val = val.contiguous()
@@ -194,8 +206,14 @@ class SelfPlayEngine(object):
             pp, vp = _lib.ptr(pol), _lib.ptr(val)
         else:
             pp, vp, k_used = None, None, 0
-        _lib.check(self.lib.sgo_step(self.ctx, pp, vp, C.c_int(k_used), _lib.stream_ptr(), C.byref(self.status)),
-                   "sgo_step")
+        if self.fused_pack:
+            next_k = self._draw_k()              # one symmetry for the batch this step lists (symmetry.py:127-132)
+            _lib.check(self.lib.sgo_step_fused(self.ctx, pp, vp, C.c_int(k_used), C.c_int(next_k), _lib.ptr(self.nn_in),
+                                               _lib.stream_ptr(), C.byref(self.status)), "sgo_step_fused")
+            self._k_packed = next_k
+        else:
+            _lib.check(self.lib.sgo_step(self.ctx, pp, vp, C.c_int(k_used), _lib.stream_ptr(), C.byref(self.status)),
+                       "sgo_step")
         self._primed = True
         self.n_steps += 1
         if self.status.error and self.raise_on_error:

@@ -206,8 +206,51 @@ class _SymNet(object):
         return pol, val
 
 
+class _Padded32(object):
+    """A stub net behind the fused inference net's input contract (fp16 NHWC with the channels zero-padded to 32): makes
+    the engine take the fused board_advance + nn_input_pack step (sgo_step_fused) while the evaluation stays the
+    rounding-free hash of the 17 real planes -- any wrong bit in a packed row changes the game."""
+    in_channels = 32
+
+    def __init__(self, net):
+        self.net, self.name = net, net.name
+
+    def predict_on_batch(self, X):
+        assert X.shape[-1] == 32 and float(X[..., 17:].abs().max()) == 0.0
+        return self.net.predict_on_batch(X[..., :17])
+
+
+@pytest.mark.parametrize("fn", ["async_02.npz", "async_05.npz", "async_07.npz", "async_08.npz"])
+def test_fused_advance_and_pack_reproduces_the_golden_games(L, fn):
+    """sgo_step_fused (one kernel: parent record -> child record + legal bits + the child's network-input row) against the
+    reference's goldens: 9x9 and 5x5 games incl. the 'No best leaf' path, 19x19 at 400 sims and at 1 600 sims / 32-leaf rounds."""
+    from sejonggo_amd.stub_nets import make_stub
+    z = load(fn)
+    S = int(z["size"])
+    net = _Padded32(make_stub(bytes(z["net"]).decode(), S))
+    eng = _engine(z, net)
+    assert eng.fused_pack and eng.layout == 2
+    games = eng.run()
+    gd = games[0]
+    assert len(gd["moves"]) == len(z["move_index"])
+    for i, mv in enumerate(gd["moves"]):
+        a = mv["move"][0] + S * mv["move"][1] if mv["move"][1] != S else S * S
+        assert a == z["move_index"][i] and mv["policy"].tobytes() == z["move_policy"][i].tobytes(), i
+        assert mv["value"].tobytes() == z["move_value"][i].tobytes(), i
+    assert gd["result"] == bytes(z["result"]).decode()
+    assert eng.status.total_evals == int(z["n_predict"]) and eng.status.none_events == int(z["none_events"])
+    eng.close()
+    k = len(z["move_index"]) - 1
+    eng = _engine(z, net, halt_at=k)
+    eng.run()
+    buf, nn, ne = eng.tree_serialize(0)
+    assert nn == z["pm_n_nodes"][k] and hashlib.sha1(buf.tobytes()).digest()[:16] == z["pm_tree_hash"][k].tobytes()
+    eng.close()
+
+
+@pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("mode", [1, 2, 3, 4, 5, 6, 7, "avg8"])
-def test_symmetry_modes_equal_the_oracle(L, mode):
+def test_symmetry_modes_equal_the_oracle(L, mode, fused):
     from oracle import oracle as ora
     from sejonggo_amd.engine import SelfPlayEngine
     from sejonggo_amd.stub_nets import make_stub
@@ -216,8 +259,9 @@ def test_symmetry_modes_equal_the_oracle(L, mode):
     rng = np.random.RandomState(21)
     noises = rng.dirichlet([0.03] * (S * S + 1), size=2)
     uni = rng.random_sample((2, nm))
-    eng = SelfPlayEngine(net, size=S, n_games=2, sims=sims, energy=E, stop_exploration=3, num_moves=nm, komi=5.5,
-                         symmetry=mode)
+    eng = SelfPlayEngine(_Padded32(net) if fused else net, size=S, n_games=2, sims=sims, energy=E, stop_exploration=3,
+                         num_moves=nm, komi=5.5, symmetry=mode)
+    assert eng.fused_pack == (fused and mode != "avg8")      # the 8-fold average packs eight times: stand-alone kernel
     eng.start_games([0, 1], noises=noises, uniforms=uni)
     games = eng.run()
     ks = list(range(8)) if mode == "avg8" else [mode]
