@@ -122,6 +122,12 @@ int sgo_conv3x3_bias_act_dev(int n, int h, int w, int c, int k, int pad, const v
  * point above dispatches here whenever the shape fits.  Same layouts. */
 int sgo_conv3x3_tower_dev(int n, int h, int w, const void *d_x, const void *d_w, const void *d_bias, const void *d_skip,
                           void *d_y, void *stream);
+/* Tile order of the tower kernel's launches: 1 = every XCD walks a contiguous range of pixel tiles (default: the halo rows
+ * a tile shares with its neighbour are then in that XCD's L2), 0 = identity.  Returns the previous mode; other values query. */
+int sgo_conv_tile_order(int mode);
+/* Test hook: cap the samples per launch of sgo_conv3x3_tower_dev (0 = no cap) so that the slice loop, which otherwise
+ * needs tensors beyond 2^31 bytes, can be exercised on small inputs.  Returns the previous cap; negative values query. */
+long sgo_conv_tower_slice_cap(long cap);
 /* Back-end selection of sgo_conv3x3_bias_act_dev: 0 = hand-written kernel where the shape fits (default), 1 = generic
  * path for every shape (A/B measurements).  Returns the previous mode; any other value only queries. */
 int sgo_conv_backend(int mode);

@@ -65,11 +65,24 @@ using Arr5 = std::array<ck::index_t, 5>;
 
 namespace {
 int g_conv_backend = 0;   // 0: hand-written kernel where the shape fits, 1: generic path only
+long g_tower_slice_cap = 0;   // > 0: samples per launch of the tower kernel are capped (tests of the slice loop)
+}
+
+extern "C" long sgo_conv_tower_slice_cap(long cap) {
+    const long old = g_tower_slice_cap;
+    if (cap >= 0) g_tower_slice_cap = cap;
+    return old;
 }
 
 extern "C" int sgo_conv_backend(int mode) {
     const int old = g_conv_backend;
     if (mode == 0 || mode == 1) g_conv_backend = mode;
+    return old;
+}
+
+extern "C" int sgo_conv_tile_order(int mode) {
+    const int old = sgo_conv8w::tile_order();
+    if (mode == 0 || mode == 1) sgo_conv8w::tile_order() = mode;
     return old;
 }
 
@@ -87,6 +100,10 @@ extern "C" int sgo_conv3x3_tower_dev(int n, int h, int w, const void *d_x, const
     // the kernel addresses pixels with 32-bit byte offsets: batches beyond 2^31 bytes per tensor run in slices
     const long per = (long)h * w * sgo_conv8w::ROWB;
     long max_n = ((1L << 31) - 1) / per;
+    // ... and splits pixel indices by magic-number division, exact while (M + 256) * (h*w) < 2^32
+    const long max_n_div = (long)(((1ULL << 32) - 1) / (unsigned long long)(h * w) - 256) / ((long)h * w);
+    if (max_n_div < max_n) max_n = max_n_div;
+    if (g_tower_slice_cap > 0 && g_tower_slice_cap < max_n) max_n = g_tower_slice_cap;   // test hook: exercise the slice loop
     if (max_n > 256) max_n -= max_n % 256;
     if (max_n < 1) { set_error("sgo_conv3x3_tower_dev: one sample exceeds the addressable range"); return SGO_ERR_ARG; }
     for (long n0 = 0; n0 < n; n0 += max_n) {

@@ -70,7 +70,8 @@ constexpr int LW0 = 0, LB0 = 40960, LB1 = 73728, LW1 = 106496, LZ = 147456, LZ_B
 template <bool HAS_SKIP>
 __global__ __launch_bounds__(512) void k_conv8w(const char *__restrict__ xb, const char *__restrict__ wb,
                                                  const _Float16 *__restrict__ bias, const char *__restrict__ skipb,
-                                                 char *__restrict__ yb, int M, int H, int W, unsigned magicHW, unsigned magicW
+                                                 char *__restrict__ yb, int M, int H, int W, unsigned magicHW, unsigned magicW,
+                                                 int xcd_q, int xcd_r
 #ifdef SGO_CONV8_STAMPS
                                                  , long long *stamps
 #endif
@@ -84,7 +85,15 @@ __global__ __launch_bounds__(512) void k_conv8w(const char *__restrict__ xb, con
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 2, wc = wid & 3;
     const int swid = wid;
-    const int tile = blockIdx.x;
+    // Tile order.  Workgroups are dealt to the 8 XCDs round-robin (workgroup b runs on XCD b % 8, each XCD has its own
+    // L2); neighbouring tiles share 2 (w + 1) halo rows of x.  With the grid split as tiles = 8 q + r, XCD c gets the
+    // CONTIGUOUS tile range [c (q+1), ...) for c < r and [r (q+1) + (c - r) q, ...) otherwise, walked in launch order: the
+    // halo rows a tile needs were just fetched into the same L2 by its predecessor.  xcd_q < 0: identity order.
+    int tile = blockIdx.x;
+    if (xcd_q >= 0) {
+        const int c = tile & 7, i = tile >> 3;
+        tile = (c < xcd_r) ? c * (xcd_q + 1) + i : xcd_r * (xcd_q + 1) + (c - xcd_r) * xcd_q + i;
+    }
     const int HW = H * W, HALO = W + 1, NROWS = 256 + 2 * HALO;
 
     if (tid < LZ_BYTES / 16) *reinterpret_cast<intx4 *>(smem + LZ + tid * 16) = intx4{0, 0, 0, 0};
@@ -408,6 +417,12 @@ __global__ __launch_bounds__(512) void k_conv8w(const char *__restrict__ xb, con
 
 // x: [n][h][w][256] fp16, wgt: [256][3][3][256] fp16, bias: fp16[256], skip (may be null) / y: [n][h][w][256] fp16.
 // Requires w <= 19 and n*h*w*512 < 2^31 (the caller slices larger batches).
+// tile order of the launches: 1 = XCD-contiguous (default), 0 = identity (A/B measurements)
+static inline int &tile_order() {
+    static int mode = 1;
+    return mode;
+}
+
 static inline int launch(int n, int h, int w, const void *x, const void *wgt, const void *bias, const void *skip, void *y,
                          hipStream_t st
 #ifdef SGO_CONV8_STAMPS
@@ -416,12 +431,16 @@ static inline int launch(int n, int h, int w, const void *x, const void *wgt, co
                          ) {
     const long M = (long)n * h * w;
     if (M <= 0 || M * ROWB >= (1L << 31) || w > MAXW || w < 1 || h < 1) return -1;
+    // the pixel -> (sample, y, x) split uses magic-number division, exact only while p * (h*w) < 2^32 for every pixel
+    // index the kernel forms (p < M + 256)
+    if ((unsigned long long)(M + 256) * (unsigned long long)(h * w) >= (1ULL << 32)) return -1;
     const int tiles = (int)((M + 255) / 256);
+    const int xq = tile_order() ? tiles / 8 : -1, xr = tiles % 8;
     const unsigned mhw = (unsigned)(((1ULL << 32) + (unsigned)(h * w) - 1) / (unsigned)(h * w)), mw = (unsigned)(((1ULL << 32) + (unsigned)w - 1) / (unsigned)w);
 #ifdef SGO_CONV8_STAMPS
-#define SGW_ARGS (const char *)x, (const char *)wgt, (const _Float16 *)bias, (const char *)skip, (char *)y, (int)M, h, w, mhw, mw, stamps
+#define SGW_ARGS (const char *)x, (const char *)wgt, (const _Float16 *)bias, (const char *)skip, (char *)y, (int)M, h, w, mhw, mw, xq, xr, stamps
 #else
-#define SGW_ARGS (const char *)x, (const char *)wgt, (const _Float16 *)bias, (const char *)skip, (char *)y, (int)M, h, w, mhw, mw
+#define SGW_ARGS (const char *)x, (const char *)wgt, (const _Float16 *)bias, (const char *)skip, (char *)y, (int)M, h, w, mhw, mw, xq, xr
 #endif
     if (skip) hipLaunchKernelGGL(k_conv8w<true>, dim3(tiles), dim3(512), 0, st, SGW_ARGS);
     else hipLaunchKernelGGL(k_conv8w<false>, dim3(tiles), dim3(512), 0, st, SGW_ARGS);

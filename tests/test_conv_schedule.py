@@ -1,0 +1,176 @@
+"""CPU model of the hand-counted `s_waitcnt vmcnt(N)` waits of the tower convolution kernel (csrc/sgo_conv8w.hpp).
+
+The kernel never waits for vmcnt(0) inside its K loop: each wait names how many of the wave's YOUNGEST vector-memory
+operations may still be in flight, and everything older -- in particular the LDS-DMA whose data the next phase reads --
+has then landed (vector-memory operations of a wave retire in issue order).  A wrong count is a data race that only shows
+as run-to-run differences on the GPU; round 1 shipped such a bug for a few hours (the window piece of a K-tile is issued
+by SOME waves only -- those whose rows of the piece exist -- and the count must follow the wave).  This model replays,
+per wave, the order in which the kernel issues its DMAs / loads / stores and checks at every wait that what is read next is
+older than the N youngest.  It is tied to the source: the wait expressions and the piece condition are read from the
+header and the test fails when they change, so the model cannot silently drift from the kernel."""
+import os
+import re
+
+HDR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sejonggo_amd", "csrc", "sgo_conv8w.hpp")
+
+
+def _src():
+    return open(HDR).read()
+
+
+def test_model_is_in_step_with_the_kernel_source():
+    s = _src()
+    # the piece condition: taps 0..4 of a chunk stage the next chunk's window; piece 4 only by waves whose rows exist
+    assert "#define SGW_WP_COND(CP, TP) ((TP) >= 0 && (TP) < 5 && ((CP) == 0 || kk == 0) && ((TP) < 4 || (4 * 8 + swid) * 8 < NROWS))" in s
+    # phase B: 4 weight DMAs, then the piece, then the counted wait
+    assert "SGW_WAIT_B(4 + (wp_ ? 1 : 0) + (wpprev_ ? 1 : 0));" in s
+    assert re.search(r"SGW_STAGE_BK\(BUF_, 0, koff_\);\s*\\\s*SGW_STAGE_BK\(BUF_, 1, koff_\);\s*\\\s*const bool wp_", s)
+    assert "_Pragma(\"unroll\") for (int i_ = 0; i_ < 2; i_++)" in s          # 2 DMAs per (buffer, granule) and wave
+    assert "if (id_ * 8 < NROWS)" in s and "const int id_ = (pc) * 8 + swid;" in s
+    # prologue: 5 pieces, weights of K-tiles 0 and 1, wait for all but K-tile 1's
+    assert re.search(r"for \(int pc = 0; pc < 5; pc\+\+\) SGW_STAGE_W\(0, pc\);\s*SGW_STAGE_B\(0, 0, 0\);\s*SGW_STAGE_B\(0, 1, 0\);\s*"
+                     r"SGW_STAGE_B\(1, 0, 1\);\s*SGW_STAGE_B\(1, 1, 1\);", s)
+    assert "SGW_VMWAIT(4);\n    asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\");   // the zero row" in s
+    # tail of the loop and the epilogue
+    assert "const bool last2_ = (CP) == 1 && (T) >= 7 && kk == 1;" in s
+    assert "SGW_VMWAIT(0);   /* K-tile 34: K-tile 35's weights */" in s
+    assert "if (HAS_SKIP && (CP) == 1 && (T) == 8 && kk == 1) SGW_SKIP_LO(0);" in s and "if (HAS_SKIP) SGW_SKIP_LO(1);" in s
+    assert s.count("asm volatile(\"s_waitcnt vmcnt(8)\" ::: \"memory\");") == 1
+    assert "for (int j = 0; j < 8; j++) SGW_STAGE_SKIP(1, j);" in s
+
+
+class Wave(object):
+    """Issue log of one wave: every vector-memory operation gets a tag; wait(n, need) checks `need` is older than the n youngest."""
+
+    def __init__(self):
+        self.ops = []
+
+    def issue(self, tag):
+        self.ops.append(tag)
+
+    def wait(self, n, need, where):
+        young = self.ops[len(self.ops) - n:] if n else []
+        for tag in need:
+            assert tag in self.ops, "%s: %r was never issued" % (where, tag)
+            assert tag not in young, "%s: vmcnt(%d) leaves %r in flight, but it is read next" % (where, n, tag)
+
+
+def piece_cond(CP, TP, kk, wid, nrows):
+    return TP >= 0 and TP < 5 and (CP == 0 or kk == 0) and (TP < 4 or (4 * 8 + wid) * 8 < nrows)
+
+
+def run_wave(wid, W, has_skip, count_piece_per_wave=True):
+    """Replays one wave.  count_piece_per_wave=False is the bug of commit 3e0d1de's parent: the wait counted the piece as
+    if every wave issued it."""
+    nrows = 256 + 2 * (W + 1)
+    w = Wave()
+    for pc in range(5):
+        if (pc * 8 + wid) * 8 < nrows:
+            w.issue(("win", 0, pc))
+    for t in (0, 1):
+        for g in (0, 1):
+            for i in (0, 1):
+                w.issue(("wgt", t, g, i))
+    need = [("wgt", 0, g, i) for g in (0, 1) for i in (0, 1)] + [("win", 0, pc) for pc in range(5) if (pc * 8 + wid) * 8 < nrows]
+    w.wait(4, need, "prologue")
+    for kk in (0, 1):
+        for CP in (0, 1):
+            for T in range(9):
+                t = 18 * kk + 9 * CP + T
+                cc = 2 * kk + CP
+                where = "K-tile %d (wave %d, w %d)" % (t, wid, W)
+                # phase A reads weights[t] and (G = 0) the window of chunk cc: both must have landed at an EARLIER wait
+                if has_skip and CP == 1 and T == 8 and kk == 1:
+                    for j in range(4):
+                        w.issue(("skip", 0, j))
+                last2 = CP == 1 and T >= 7 and kk == 1
+                if not last2:
+                    for g in (0, 1):
+                        for i in (0, 1):
+                            w.issue(("wgt", t + 2, g, i))
+                    wp, wpprev = piece_cond(CP, T, kk, wid, nrows), piece_cond(CP, T - 1, kk, wid, nrows)
+                    if wp:
+                        w.issue(("win", cc + 1, T))
+                    if count_piece_per_wave:
+                        n = 4 + (1 if wp else 0) + (1 if wpprev else 0)
+                    else:
+                        gen = lambda TP: TP >= 0 and TP < 5 and (CP == 0 or kk == 0)
+                        n = 4 + (1 if gen(T) else 0) + (1 if gen(T - 1) else 0)
+                    # the next K-tile's phase A reads weights[t+1]
+                    need = [("wgt", t + 1, g, i) for g in (0, 1) for i in (0, 1)]
+                    # the first K-tile of the next chunk reads that chunk's window: all its pieces must be retired by then
+                    if T == 8 and cc < 3:
+                        need += [("win", cc + 1, pc) for pc in range(5) if (pc * 8 + wid) * 8 < nrows]
+                    w.wait(n, need, where)
+                elif T == 7:
+                    w.wait(0, [("wgt", 35, g, i) for g in (0, 1) for i in (0, 1)], where)
+                else:
+                    if has_skip:
+                        for j in range(4, 8):
+                            w.issue(("skip", 0, j))
+    # epilogue: bias (4 loads), the hi half's skip rows, then per half: wait, process, 8 row stores
+    for q in range(4):
+        w.issue(("bias", q))
+    if has_skip:
+        for j in range(8):
+            w.issue(("skip", 1, j))
+    for hf in (0, 1):
+        if has_skip:
+            w.wait(8, [("skip", hf, j) for j in range(8)] + [("bias", q) for q in range(4)], "epilogue half %d" % hf)
+        elif hf == 0:
+            w.wait(0, [("bias", q) for q in range(4)], "epilogue (no skip)")
+        for j in range(8):
+            w.issue(("store", hf, j))
+    return w
+
+
+def test_every_counted_wait_retires_what_is_read_next():
+    for W in (5, 7, 9, 13, 17, 19):
+        for has_skip in (False, True):
+            for wid in range(8):
+                run_wave(wid, W, has_skip)
+
+
+def test_window_pieces_are_retired_two_k_tiles_before_their_chunk_starts():
+    """Stronger than needed for correctness, and what the kernel's comment promises: a chunk's window pieces are issued in
+    taps 0..4 and all retired by the wait of tap 6 (the barrier of tap 6 publishes them to the other waves)."""
+    for W in (7, 17, 19):
+        for wid in range(8):
+            nrows = 256 + 2 * (W + 1)
+            w = Wave()
+            ops_at_wait = {}
+            # replay again, recording the youngest set after each wait of chunk 0
+            for pc in range(5):
+                if (pc * 8 + wid) * 8 < nrows:
+                    w.issue(("win", 0, pc))
+            for t in (0, 1):
+                for g in (0, 1):
+                    for i in (0, 1):
+                        w.issue(("wgt", t, g, i))
+            for T in range(9):
+                for g in (0, 1):
+                    for i in (0, 1):
+                        w.issue(("wgt", T + 2, g, i))
+                wp, wpprev = piece_cond(0, T, 0, wid, nrows), piece_cond(0, T - 1, 0, wid, nrows)
+                if wp:
+                    w.issue(("win", 1, T))
+                n = 4 + (1 if wp else 0) + (1 if wpprev else 0)
+                ops_at_wait[T] = set(w.ops[len(w.ops) - n:])
+            assert not any(tag[0] == "win" for tag in ops_at_wait[6]), (W, wid)
+
+
+def test_the_model_catches_the_round_1_race():
+    """Counting the window piece as if every wave issued it (the bug fixed in 3e0d1de) must be flagged for the waves that
+    do not issue piece 4 -- which waves those are depends on the board width."""
+    import pytest
+    flagged = []
+    for W in (7, 17, 19):
+        for wid in range(8):
+            try:
+                run_wave(wid, W, True, count_piece_per_wave=False)
+            except AssertionError as e:
+                assert "in flight" in str(e)
+                flagged.append((W, wid))
+    nrows17 = 256 + 2 * 18
+    assert (17, 7) in flagged and all(((4 * 8 + wid) * 8 >= 256 + 2 * (W + 1)) for W, wid in flagged)
+    assert [(W, wid) for W, wid in flagged if W == 17] == [(17, wid) for wid in range(8) if (32 + wid) * 8 >= nrows17]

@@ -548,6 +548,57 @@ def test_fused_conv_kernel_matches_torch(L):
         assert err <= 2e-2 * top, (n, h, c, k, pad, with_skip, err)
 
 
+def test_tower_conv_tile_order_slices_and_bounds(L):
+    """The tower kernel's launch plumbing: (1) both tile orders (identity, XCD-contiguous incl. grids that are not a
+    multiple of 8) give identical bits; (2) the slice loop of sgo_conv3x3_tower_dev, normally reached only beyond 2^31 bytes
+    per tensor, exercised through the sample cap hook on ragged slice sizes; (3) shapes whose pixel index arithmetic would
+    leave the range where the kernel's magic-number division is exact are sliced, not mis-computed (h x w = 64 x 19)."""
+    import torch
+    import torch.nn.functional as F
+    lib = L.load()
+    st = torch.cuda.current_stream().cuda_stream
+    torch.manual_seed(7)
+    w = (torch.randn(256, 3, 3, 256, device="cuda") * 0.03).half()
+    b = torch.randn(256, device="cuda").half()
+
+    def conv(x, skip):
+        y = torch.full_like(x, 5.0)
+        L.check(lib.sgo_conv3x3_tower_dev(x.shape[0], x.shape[1], x.shape[2], x.data_ptr(), w.data_ptr(), b.data_ptr(),
+                                          skip.data_ptr(), y.data_ptr(), st))
+        return y
+
+    for n in (1, 9, 37, 300):                       # 2, 11, 42, 339 tiles: every remainder class of tiles % 8 shows up
+        x = (torch.randn(n, 17, 17, 256, device="cuda") * 0.5).half()
+        skip = torch.randn_like(x)
+        old = lib.sgo_conv_tile_order(0)
+        try:
+            y0 = conv(x, skip)
+            lib.sgo_conv_tile_order(1)
+            y1 = conv(x, skip)
+        finally:
+            lib.sgo_conv_tile_order(old)
+        assert torch.equal(y0, y1), n
+    x = (torch.randn(700, 17, 17, 256, device="cuda") * 0.5).half()
+    skip = torch.randn_like(x)
+    whole = conv(x, skip)
+    for cap in (1, 255, 256, 300):
+        assert lib.sgo_conv_tower_slice_cap(cap) == 0
+        try:
+            assert torch.equal(conv(x, skip), whole), cap
+        finally:
+            lib.sgo_conv_tower_slice_cap(0)
+    # a tall board: 64 x 19 = 1216 points per sample; (M + 256) * 1216 reaches 2^32 near 2 900 samples, far below the byte limit
+    n, h, wd = 3000, 64, 19
+    x = (torch.randn(n, h, wd, 256, device="cuda") * 0.5).half()
+    skip = torch.randn_like(x)
+    y = conv(x, skip)
+    for i in (0, 1499, 2895, 2896, 2999):
+        ref = F.conv2d(x[i:i + 1].float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), b.float(), padding=1).permute(0, 2, 3, 1)
+        ref = torch.relu(ref + skip[i:i + 1].float())
+        err = (y[i:i + 1].float() - ref).abs()
+        assert bool((err <= 2e-3 * ref.abs() + 2e-3).all()), (i, float(err.max()))
+
+
 def test_tower_conv_kernel(L):
     """sgo_conv3x3_tower_dev, the hand-written CDNA4 kernel (csrc/sgo_conv8w.hpp): against torch conv2d in fp32 (tolerance:
     fp16 output rounding, 2e-3 relative + 2e-3 absolute), against the generic back end, bit-identical across repeated

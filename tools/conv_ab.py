@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""A/B of runtime knobs of the tower convolution (libsgo_hip.so) in ONE process, arms interleaved launch by launch so
+that clock / temperature drift hits both alike (MI355X_MICROARCH.md 'DVFS give-back': never compare separate runs).
+usage: conv_ab.py [n=8192] [iters=40]      data: ReLU(random) activations + skip, what the tower sees."""
+import sys
+import os
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+from sejonggo_amd import _lib as L
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+    iters = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+    lib = L.require_gpu()
+    h = w = 17
+    torch.manual_seed(0)
+    x = torch.relu(torch.randn(n, h, w, 256, device="cuda", dtype=torch.float16) * 0.5)
+    skip = torch.relu(torch.randn(n, h, w, 256, device="cuda", dtype=torch.float16) * 0.5)
+    wt = (torch.randn(256, 3, 3, 256, device="cuda", dtype=torch.float16) * 0.03)
+    b = torch.randn(256, device="cuda", dtype=torch.float16) * 0.1
+    y = torch.empty_like(x)
+    st = L.stream_ptr()
+    fl = 2.0 * n * h * w * 9 * 256 * 256
+
+    def run():
+        L.check(lib.sgo_conv3x3_tower_dev(n, h, w, L.ptr(x), L.ptr(wt), L.ptr(b), L.ptr(skip), L.ptr(y), st))
+
+    arms = [("identity tile order", 0), ("XCD-contiguous tile order", 1)]
+    outs = {}
+    for name, mode in arms:
+        lib.sgo_conv_tile_order(mode)
+        run()
+        torch.cuda.synchronize()
+        outs[name] = y.clone()
+    assert torch.equal(outs[arms[0][0]], outs[arms[1][0]]), "tile order changed the result"
+    for _ in range(10):
+        run()
+    ms = {name: 0.0 for name, _ in arms}
+    evs = []
+    for it in range(iters):
+        for name, mode in arms:
+            lib.sgo_conv_tile_order(mode)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            run()
+            e1.record()
+            evs.append((name, e0, e1))
+    torch.cuda.synchronize()
+    for name, e0, e1 in evs:
+        ms[name] += e0.elapsed_time(e1)
+    for name, _ in arms:
+        t = ms[name] / iters
+        print("%-28s %.4f ms  %.0f TFLOP/s" % (name, t, fl / t / 1e9), flush=True)
+    lib.sgo_conv_tile_order(1)
+
+
+if __name__ == "__main__":
+    main()
