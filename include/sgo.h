@@ -36,6 +36,7 @@ extern "C" {
 #define SGO_OK 0
 #define SGO_ERR_ARG (-1)          /* bad size / null pointer / unsupported board size */
 #define SGO_ERR_HIP (-2)          /* HIP runtime error, see sgo_last_error() */
+#define SGO_ERR_UNSUPPORTED (-3)  /* no hand-written kernel for this shape; the caller takes another route */
 #define SGO_ERR_OCCUPIED (-101)   /* play.py:233-234 assert: stone on an occupied point */
 #define SGO_ERR_RANGE (-102)      /* coordinates outside the board (IndexError in the reference) */
 #define SGO_ERR_CAPACITY (-201)   /* a game's tree-block pool is exhausted */
@@ -112,25 +113,26 @@ int sgo_nn_pack_dev(int S, int n, const uint32_t *d_packed, const int32_t *d_idx
 int sgo_bias_act_dev(long n_elems, int channels, const void *d_x, const void *d_bias, const void *d_skip, void *d_out,
                      void *stream);
 
-/* The tower convolution of the resident net with the epilogue fused: y = relu(conv3x3(x, w) + bias[k] (+ skip)),
+/* The 3x3 convolutions of the resident net with the epilogue fused: y = relu(conv3x3(x, w) + bias[k] (+ skip)),
  * stride 1, pad 0 or 1, NHWC fp16 (x [n][h][w][c], w [k][3][3][c] = PyTorch channels_last weight storage,
- * y / skip [n][ho][wo][k]), fp32 accumulation on MFMA.  c and k must be multiples of 8. */
+ * y / skip [n][ho][wo][k]), fp32 accumulation on MFMA.  Dispatches to the two hand-written kernels below; any other
+ * shape returns SGO_ERR_UNSUPPORTED (net.FusedInferenceNet then runs that layer through the framework's convolution and
+ * sgo_bias_act_dev). */
 int sgo_conv3x3_bias_act_dev(int n, int h, int w, int c, int k, int pad, const void *d_x, const void *d_w,
                              const void *d_bias, const void *d_skip, void *d_y, void *stream);
 
-/* The hand-written CDNA4 kernel for the tower shape (c = k = 256, pad 1, w <= 19; csrc/sgo_conv8w.hpp); the entry
- * point above dispatches here whenever the shape fits.  Same layouts. */
+/* The hand-written CDNA4 kernel for the tower shape (c = k = 256, pad 1, w <= 19; csrc/sgo_conv8w.hpp).  Same layouts. */
 int sgo_conv3x3_tower_dev(int n, int h, int w, const void *d_x, const void *d_w, const void *d_bias, const void *d_skip,
                           void *d_y, void *stream);
+/* The hand-written CDNA4 kernel for the stem (c = 32: the 17 input planes zero-padded, k = 256, pad 0, no skip;
+ * csrc/sgo_stem.hpp; model.py:57-60).  x [n][h][w][32] is the network-input row format of sgo_step_fused / layout 2. */
+int sgo_conv3x3_stem_dev(int n, int h, int w, const void *d_x, const void *d_w, const void *d_bias, void *d_y, void *stream);
 /* Tile order of the tower kernel's launches: 1 = every XCD walks a contiguous range of pixel tiles (default: the halo rows
  * a tile shares with its neighbour are then in that XCD's L2), 0 = identity.  Returns the previous mode; other values query. */
 int sgo_conv_tile_order(int mode);
-/* Test hook: cap the samples per launch of sgo_conv3x3_tower_dev (0 = no cap) so that the slice loop, which otherwise
- * needs tensors beyond 2^31 bytes, can be exercised on small inputs.  Returns the previous cap; negative values query. */
+/* Test hook: cap the samples per launch of sgo_conv3x3_tower_dev / _stem_dev (0 = no cap) so that the slice loop, which
+ * otherwise needs tensors beyond 2^31 bytes, can be exercised on small inputs.  Returns the previous cap; negative = query. */
 long sgo_conv_tower_slice_cap(long cap);
-/* Back-end selection of sgo_conv3x3_bias_act_dev: 0 = hand-written kernel where the shape fits (default), 1 = generic
- * path for every shape (A/B measurements).  Returns the previous mode; any other value only queries. */
-int sgo_conv_backend(int mode);
 
 /* ---- self-play engine: virtual-loss PUCT + game loop, many games resident on one GPU ------------ */
 /* Replaces nomodel_self_play.py:59-82 async_simulate2, :114-140 select_play, :142-271 play_game_async,

@@ -131,8 +131,9 @@ class FusedInferenceNet(object):
 
     * input NHWC fp16 with channels zero-padded 17 -> 32 (k_nn_pack layout 2), so the stem runs on an
       MFMA-friendly K instead of MIOpen's slow path for odd channel counts;
-    * every 3x3 convolution is a bias-free MIOpen/CK implicit GEMM followed by ONE hand-written epilogue pass
-      (libsgo_hip.so k_bias_act: bias + optional skip + ReLU) instead of separate bias / add / clamp passes;
+    * every 3x3 convolution of the reference's topology runs in a hand-written CDNA4 kernel of libsgo_hip.so with bias
+      (+ skip) + ReLU fused: the tower (csrc/sgo_conv8w.hpp) and the stem (csrc/sgo_stem.hpp); other channel counts
+      (small test nets) fall back to the framework's convolution + ONE hand-written epilogue pass (k_bias_act);
     * both 1x1 head convolutions are one [n*t*t, C] x [C, 4] GEMM on the channels-last view.
     """
     in_channels = 32
@@ -186,12 +187,19 @@ class FusedInferenceNet(object):
                                           torch.cuda.current_stream().cuda_stream), "sgo_bias_act_dev")
         return y
 
+    @staticmethod
+    def has_kernel(c, k, pad, wd, skip):
+        """Shapes libsgo_hip.so has a hand-written kernel for: the tower (256 -> 256, 'same', board width <= 19) and the
+        stem (32 -> 256, 'valid')."""
+        return (c == 256 and k == 256 and pad == 1 and wd <= 19) or (c == 32 and k == 256 and pad == 0 and skip is None)
+
     def _conv(self, x, w, b, pad, skip=None):
-        """relu(conv3x3(x, w) + b (+ skip)) on NCHW views of channels-last tensors."""
-        if not self.fused_conv:
-            return self._epilogue(F.conv2d(x, w, None, padding=pad), b, skip=skip)
+        """relu(conv3x3(x, w) + b (+ skip)) on NCHW views of channels-last tensors.  Other channel counts than the
+        reference's (small test nets) go through the framework's convolution + the fused epilogue pass."""
         n, c, h, wd = x.shape
         k = w.shape[0]
+        if not self.fused_conv or not self.has_kernel(c, k, pad, wd, skip):
+            return self._epilogue(F.conv2d(x, w, None, padding=pad), b, skip=skip)
         y = torch.empty((n, k, h + 2 * pad - 2, wd + 2 * pad - 2), dtype=x.dtype, device=x.device,
                         memory_format=torch.channels_last)
         timed = self.conv_events is not None and c == k == 256 and pad == 1

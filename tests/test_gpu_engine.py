@@ -520,13 +520,19 @@ def test_worker_survives_a_slot_that_outgrows_its_block_pool(L, tmp_path, monkey
 
 
 def test_fused_conv_kernel_matches_torch(L):
-    """sgo_conv3x3_bias_act_dev (MFMA implicit GEMM with our bias/skip/ReLU epilogue) against torch conv2d in fp32."""
+    """sgo_conv3x3_bias_act_dev (dispatch to the hand-written tower / stem kernels, bias / skip / ReLU fused) against torch
+    conv2d in fp32; shapes without a hand-written kernel are refused loudly (SGO_ERR_UNSUPPORTED), never computed elsewhere."""
     import torch
     import torch.nn.functional as F
     lib = L.load()
     torch.manual_seed(0)
+    x = torch.zeros(3, 7, 7, 64, device="cuda", dtype=torch.float16)
+    rc = lib.sgo_conv3x3_bias_act_dev(3, 7, 7, 64, 64, 1, x.data_ptr(), x.data_ptr(), x.data_ptr(), None, x.data_ptr(),
+                                      torch.cuda.current_stream().cuda_stream)
+    assert rc == L.SGO_ERR_UNSUPPORTED and b"no hand-written kernel" in lib.sgo_last_error()
     for (n, h, c, k, pad, with_skip) in [(8, 17, 256, 256, 1, True), (8, 17, 256, 256, 1, False), (5, 19, 32, 256, 0, False),
-                                         (3, 7, 64, 64, 1, True), (300, 17, 256, 256, 1, True),
+                                         (1, 9, 32, 256, 0, False), (300, 19, 32, 256, 0, False), (37, 5, 32, 256, 0, False),
+                                         (300, 17, 256, 256, 1, True),
                                          (15000, 17, 256, 256, 1, True)]:     # > 2^31 bytes per tensor: sliced launches
         x = (torch.randn(n, c, h, h, device="cuda") * 0.5).half().contiguous(memory_format=torch.channels_last)
         w = (torch.randn(k, c, 3, 3, device="cuda") * 0.03).half().contiguous(memory_format=torch.channels_last)
@@ -546,6 +552,46 @@ def test_fused_conv_kernel_matches_torch(L):
             err = max(err, float((y[o:o + 2048].float() - ref).abs().max()))
             top = max(top, float(ref.abs().max()))
         assert err <= 2e-2 * top, (n, h, c, k, pad, with_skip, err)
+
+
+def test_stem_conv_kernel(L):
+    """sgo_conv3x3_stem_dev, the hand-written stem kernel (csrc/sgo_stem.hpp; 'valid' 3x3, 17 planes in 32 channels -> 256):
+    against torch in fp32 within fp16 output rounding, exact on small-integer data, bit-identical across relaunches and
+    slice sizes, on the real input format (bit planes + the colour plane, channels 17..31 zero)."""
+    import torch
+    import torch.nn.functional as F
+    lib = L.load()
+    st = torch.cuda.current_stream().cuda_stream
+    torch.manual_seed(3)
+    for (n, h, wd) in [(1, 19, 19), (2, 9, 9), (7, 5, 5), (64, 19, 19), (333, 19, 19), (100, 13, 7)]:
+        x = torch.zeros(n, h, wd, 32, device="cuda", dtype=torch.float16)
+        x[..., :16] = (torch.rand(n, h, wd, 16, device="cuda") < 0.3).half()
+        x[..., 16] = torch.where(torch.rand(n, 1, 1, device="cuda") < 0.5, 1.0, -1.0).half()
+        w = (torch.randn(256, 3, 3, 32, device="cuda") * 0.1).half()
+        b = torch.randn(256, device="cuda").half()
+        y = torch.full((n, h - 2, wd - 2, 256), 9.0, device="cuda", dtype=torch.float16)
+        L.check(lib.sgo_conv3x3_stem_dev(n, h, wd, x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), st))
+        ref = torch.relu(F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), b.float()).permute(0, 2, 3, 1))
+        err = (y.float() - ref).abs()
+        assert bool((err <= 2e-3 * ref.abs() + 2e-3).all()), (n, h, wd, float(err.max()))
+        for cap in (0, 1, 5):
+            lib.sgo_conv_tower_slice_cap(cap)
+            try:
+                y2 = torch.full_like(y, 4.0)
+                L.check(lib.sgo_conv3x3_bias_act_dev(n, h, wd, 32, 256, 0, x.data_ptr(), w.data_ptr(), b.data_ptr(), None, y2.data_ptr(), st))
+            finally:
+                lib.sgo_conv_tower_slice_cap(0)
+            assert torch.equal(y, y2), (n, h, wd, cap)
+    # exact: integer weights / bias, 0/1 inputs -> every partial sum is an integer well inside fp16's exact range
+    n, h, wd = 50, 19, 19
+    x = torch.zeros(n, h, wd, 32, device="cuda", dtype=torch.float16)
+    x[..., :17] = torch.randint(0, 2, (n, h, wd, 17), device="cuda").half()
+    w = torch.randint(-3, 4, (256, 3, 3, 32), device="cuda").half()
+    b = torch.randint(-5, 6, (256,), device="cuda").half()
+    y = torch.empty((n, h - 2, wd - 2, 256), device="cuda", dtype=torch.float16)
+    L.check(lib.sgo_conv3x3_stem_dev(n, h, wd, x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), st))
+    ref = torch.relu(F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), b.float()).permute(0, 2, 3, 1))
+    assert torch.equal(y.float(), ref)
 
 
 def test_tower_conv_tile_order_slices_and_bounds(L):
@@ -627,14 +673,6 @@ def test_tower_conv_kernel(L):
         y1 = torch.empty_like(y)
         L.check(lib.sgo_conv3x3_bias_act_dev(n, h, wd, 256, 256, 1, x.data_ptr(), w.data_ptr(), b.data_ptr(), sp, y1.data_ptr(), st))
         assert torch.equal(y, y1)
-        # generic back end: same values up to the accumulation order
-        old = lib.sgo_conv_backend(1)
-        try:
-            y2 = torch.empty_like(y)
-            L.check(lib.sgo_conv3x3_bias_act_dev(n, h, wd, 256, 256, 1, x.data_ptr(), w.data_ptr(), b.data_ptr(), sp, y2.data_ptr(), st))
-        finally:
-            lib.sgo_conv_backend(old)
-        assert float((y.float() - y2.float()).abs().max()) <= 2e-2
         for _ in range(3):
             y3 = torch.full_like(y, 3.0)
             L.check(lib.sgo_conv3x3_tower_dev(n, h, wd, x.data_ptr(), w.data_ptr(), b.data_ptr(), sp, y3.data_ptr(), st))
