@@ -13,9 +13,11 @@ layout and ordering work on plain numpy arrays:
   * Keras flattens the heads' [t][t][2] activations channels-last, which is the order net.PolicyValueNet.forward uses, so the
     Dense kernels carry over without a permutation.
 
-Reading the HDF5 container itself needs h5py (absent in this image; `load_keras_h5` raises ImportError without it): PARITY
-UNPINNED -- no Keras file ships with the reference (`*.h5` is git-ignored there), so only the array mapping is tested
-(tests/test_host_logic.py: export -> shuffled layers -> import reproduces the network bit for bit)."""
+The HDF5 container is read through h5py where that is installed, otherwise through h5lite (this package's ctypes binding to
+libhdf5, the C library h5py itself wraps; present in this image under /opt/conda/lib).  No Keras file ships with the reference
+(`*.h5` is git-ignored there) and Keras is not installable here, so the tests write a file in Keras' documented layout
+(`save_keras_h5`) with libhdf5 and read it back: the container format is libhdf5's own, the layer / weight naming is pinned
+only by Keras' source (keras/engine/saving.py), not by a Keras-written file -- PARITY of that naming is UNPINNED."""
 import re
 
 import numpy as np
@@ -85,11 +87,24 @@ def assign_keras_layers(net, layers):
     return net
 
 
+def h5_module():
+    """h5py when it is installed, otherwise this package's ctypes binding to the same C library (h5lite); ImportError when
+    neither can be had."""
+    try:
+        import h5py
+        return h5py
+    except Exception:
+        from . import h5lite
+        if not h5lite.available():
+            raise ImportError("reading a Keras .h5 file needs h5py or the HDF5 C library (libhdf5); neither was found")
+        return h5lite
+
+
 def keras_model_name(path):
     """`model.name` of a Keras model file: the `name` of its `model_config` attribute (model.py:92 builds the model with
-    an explicit name and train.py renames it before saving).  None for a weights-only file.  Needs h5py."""
+    an explicit name and train.py renames it before saving).  None for a weights-only file."""
     import json
-    import h5py
+    h5py = h5_module()
     with h5py.File(path, "r") as f:
         cfg = f.attrs.get("model_config")
     if cfg is None:
@@ -100,8 +115,9 @@ def keras_model_name(path):
 
 
 def load_keras_h5(path, net):
-    """Read a Keras model / weights file and assign it to `net`.  Needs h5py."""
-    import h5py   # noqa: F401 -- deliberately not optional: there is no other reader for Keras' classic-format files here
+    """Read a Keras model / weights file (keras/engine/saving.py layout: group `model_weights`, attribute `layer_names`,
+    one group per layer with attribute `weight_names` and one dataset per weight) and assign it to `net`."""
+    h5py = h5_module()
     with h5py.File(path, "r") as f:
         g = f["model_weights"] if "model_weights" in f else f
         layers = []
@@ -110,3 +126,28 @@ def load_keras_h5(path, net):
             names = [n.decode() if isinstance(n, bytes) else n for n in lg.attrs["weight_names"]]
             layers.append((lname, [np.asarray(lg[n]) for n in names]))
     return assign_keras_layers(net, layers)
+
+
+def save_keras_h5(path, net, keras_version=b"2.2.2", backend=b"tensorflow"):
+    """Write `net` the way keras.Model.save lays a file out (saving.py: save_model + save_weights_to_hdf5_group): root
+    attributes keras_version / backend / model_config (JSON with the model's name), group `model_weights` with attribute
+    layer_names, one group per layer with attribute weight_names and datasets `<layer>/<weight>:0`.  (No optimizer state.)"""
+    import json
+    h5py = h5_module()
+    layers = export_keras_layers(net)
+    weight_suffix = {2: ["kernel:0", "bias:0"], 4: ["gamma:0", "beta:0", "moving_mean:0", "moving_variance:0"]}
+    with h5py.File(path, "w") as f:
+        f.attrs["keras_version"] = keras_version
+        f.attrs["backend"] = backend
+        f.attrs["model_config"] = json.dumps({"class_name": "Model", "config": {"name": net.name}}).encode("utf8")
+        g = f.create_group("model_weights")
+        g.attrs["layer_names"] = np.array([n.encode() for n, _ in layers], dtype="S")
+        g.attrs["backend"] = backend
+        g.attrs["keras_version"] = keras_version
+        for lname, arrays in layers:
+            lg = g.create_group(lname)
+            names = ["%s/%s" % (lname, sfx) for sfx in weight_suffix[len(arrays)]]
+            lg.attrs["weight_names"] = np.array([n.encode() for n in names], dtype="S")
+            for n, a in zip(names, arrays):
+                lg.create_dataset(n, data=np.asarray(a, dtype=np.float32))
+    return path

@@ -6,9 +6,9 @@ predicting_queue_worker.get_model).  Files under conf['MODEL_DIR']:
 
 * `<stem>.pt`  -- a torch checkpoint {"state_dict", "name", "size", "n_blocks", "channels"} written by
   `save_model` (read with weights_only=True);
-* `<stem>.h5`  -- the reference's Keras file (model.py:147-157): read through keras_import.load_keras_h5, which needs
-  h5py.  Without h5py an existing .h5 is an ERROR (never a silent random-init fallback: a worker would otherwise write
-  self-play data from random weights under the wrong model directory).
+* `<stem>.h5`  -- the reference's Keras file (model.py:147-157): read through keras_import.load_keras_h5 (h5py, or the
+  HDF5 C library through h5lite).  With neither available an existing .h5 is an ERROR (never a silent random-init
+  fallback: a worker would otherwise write self-play data from random weights under the wrong model directory).
 
 `load_best_model` follows model.py:147-157: conf['BEST_MODEL'] if present, otherwise the initial model `model_1`
 is created (random init), saved as `model_1.pt` and as the best model, with a loud warning -- the reference does the
@@ -62,12 +62,13 @@ def _latest_stem():
 
 
 def _need_h5py(path):
+    from .keras_import import h5_module
     try:
-        import h5py  # noqa: F401
-    except Exception:
-        raise RuntimeError("%s is a Keras HDF5 model file and h5py is not installed: cannot read it.  Install h5py, or "
-                           "convert the model to a torch checkpoint with sejonggo_amd.model.save_model(); refusing to "
-                           "fall back to random weights" % path)
+        h5_module()
+    except ImportError:
+        raise RuntimeError("%s is a Keras HDF5 model file and neither h5py nor the HDF5 C library (libhdf5) is available: "
+                           "cannot read it.  Install h5py, or convert the model to a torch checkpoint with "
+                           "sejonggo_amd.model.save_model(); refusing to fall back to random weights" % path)
 
 
 def _read_pt(path):

@@ -1,10 +1,9 @@
 """Sample writer with the reference's layout (sgfsave.py:49-79 save_self_play_data):
 SELF_PLAY_DIR/<model>/game_%05d/move_%03d/sample.h5 with datasets board f32 (1,S,S,17), policy_target f32
-(S*S+1), value_target f32 ().  With h5py the file is written through it, exactly like the reference.  h5py is not
-installed in this image (probed): then sample.h5 is produced by the spec-following minimal writer hdf5_min.py
-(superblock v2 / object header v2; not yet checked against libhdf5) and, while conf['WRITE_NPZ_TWIN'] is set, the
-same three arrays are also stored as sample.npz next to it (`convert_npz_to_h5` re-writes sample.h5 through h5py
-wherever that exists).  value_target keeps the reference's rule
+(S*S+1), value_target f32 ().  Writers, in order of preference: h5py (exactly the reference's calls); h5lite, this
+package's ctypes binding to the HDF5 C library (what h5py wraps; h5py is not installed in this image, libhdf5 is); the
+pure-Python hdf5_min.py (superblock v2 / object header v2, verified readable by libhdf5: tests/test_hdf5.py), which
+also keeps a sample.npz twin while conf['WRITE_NPZ_TWIN'] is set.  value_target keeps the reference's rule
 `1 if winner == player else -1` (sgfsave.py:56) when conf['COMPAT_Z'] is set (default), and the corrected
 outcome-from-mover's-view otherwise."""
 import os
@@ -18,6 +17,12 @@ try:
     HAVE_H5 = True
 except Exception:
     HAVE_H5 = False
+
+
+def _h5lite():
+    """The HDF5 C library through this package's ctypes binding, or None."""
+    from . import h5lite
+    return h5lite if h5lite.available() else None
 
 
 def value_target(winner, player, move_n, compat=None):
@@ -36,9 +41,14 @@ def _write_sample(directory, move_data, winner):
     board = np.asarray(move_data['board'], dtype=np.float32)
     pol = np.asarray(move_data['policy'], dtype=np.float32)
     val = np.array(vt, dtype=np.float32)
-    if HAVE_H5:
-        import h5py
-        with h5py.File(os.path.join(directory, 'sample.h5'), 'w') as f:
+    lite = None if HAVE_H5 else _h5lite()
+    if HAVE_H5 or lite is not None:
+        if HAVE_H5:
+            import h5py
+            session = h5py.File(os.path.join(directory, 'sample.h5'), 'w')
+        else:
+            session = lite.open(os.path.join(directory, 'sample.h5'), 'w')    # holds the library lock: writer THREADS call this
+        with session as f:                                                     # the same three calls as sgfsave.py:76-78
             f.create_dataset('board', data=board, dtype=np.float32)
             f.create_dataset('policy_target', data=pol, dtype=np.float32)
             f.create_dataset('value_target', data=val, dtype=np.float32)

@@ -141,3 +141,18 @@ def unit_value(kv):
     if kind == 4:
         return {int(k): int(v) for k, v in arr}
     return float(arr)
+
+
+def read_sample(path):
+    """(board, policy_target, value_target) of a sample.h5, through whatever HDF5 reader exists: h5py, the HDF5 C library
+    (h5lite), or -- for files of the pure-Python writer only -- hdf5_min's own reader."""
+    try:
+        import h5py as mod
+    except Exception:
+        from sejonggo_amd import h5lite as mod
+        if not mod.available():
+            from sejonggo_amd.hdf5_min import read_datasets
+            r = read_datasets(path)
+            return r['board'], r['policy_target'], r['value_target']
+    with mod.File(path, "r") as f:
+        return f['board'][...], f['policy_target'][...], f['value_target'][()]

@@ -130,16 +130,26 @@ def test_model_loader_branches(tmp_path):
         # a Keras file that cannot be read must not degrade to random weights
         os.remove(os.path.join(conf['MODEL_DIR'], "best_model.pt"))
         open(os.path.join(conf['MODEL_DIR'], "best_model.h5"), "wb").write(b"\\x89HDF\\r\\n\\x1a\\n" + b"\\0" * 64)
+        # (a) no HDF5 reader at all: refuse loudly; (b) a reader exists: the broken file is an error of the reader
+        from sejonggo_amd import keras_import
+        real = keras_import.h5_module
+
+        def no_reader():
+            raise ImportError("no HDF5 reader")
+        keras_import.h5_module = no_reader
         try:
-            import h5py  # noqa: F401
-            have = True
-        except Exception:
-            have = False
-        if not have:
             with pytest.raises(RuntimeError, match="h5py"):
                 M.load_best_model()
             with pytest.raises(RuntimeError, match="h5py"):
                 M.model_name("BEST")
+        finally:
+            keras_import.h5_module = real
+        try:
+            real()
+            with pytest.raises(Exception):
+                M.load_best_model()
+        except ImportError:
+            pass
     finally:
         _restore(conf, old)
 
@@ -224,16 +234,9 @@ def test_main_selfplay_end_to_end_by_fork(tmp_path):
     for g in range(3):
         f = os.path.join(str(tmp_path), "selfplay", "model_1", "game_%05d" % g, "move_000", "sample.h5")
         assert os.path.isfile(f), (f, out)
-    from sejonggo_amd.hdf5_min import read_datasets
-    from sejonggo_amd import sgfsave
+    from tests.helpers import read_sample
     d = os.path.join(str(tmp_path), "selfplay", "model_1", "game_00001", "move_000")
-    if sgfsave.HAVE_H5:
-        import h5py
-        with h5py.File(os.path.join(d, "sample.h5")) as f:
-            b, p, v = f['board'][:], f['policy_target'][:], f['value_target'][()]
-    else:
-        r = read_datasets(os.path.join(d, "sample.h5"))
-        b, p, v = r['board'], r['policy_target'], r['value_target']
+    b, p, v = read_sample(os.path.join(d, "sample.h5"))
     assert b.shape == (1, 9, 9, 17) and b.dtype == np.float32 and p.shape == (82,) and v in (1.0, -1.0)
     assert b[0, :, :, :16].sum() == 0 and (b[0, :, :, 16] == 1).all()          # move 0: empty board, black to play
     assert abs(float(p.sum()) - 1.0) < 0.3 and (p >= 0).all()                  # priors (noise-mixed), not renormalised

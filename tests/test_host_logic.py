@@ -4,7 +4,7 @@ import os
 
 import numpy as np
 
-from tests.helpers import load
+from tests.helpers import load, read_sample
 
 
 def test_game_scheduler_reserves_directories(tmp_path):
@@ -67,16 +67,7 @@ def test_sample_writer_layout(tmp_path):
         d = os.path.join(str(tmp_path), "model_0", "game_00007", "move_002")
         assert os.path.isdir(d)
         assert os.path.isfile(os.path.join(d, "sample.h5"))
-        if sgfsave.HAVE_H5:
-            import h5py
-            with h5py.File(os.path.join(d, "sample.h5")) as f:
-                b, p, v = f['board'][:], f['policy_target'][:], f['value_target'][()]
-        else:
-            from sejonggo_amd.hdf5_min import read_datasets
-            r = read_datasets(os.path.join(d, "sample.h5"))
-            b, p, v = r['board'], r['policy_target'], r['value_target']
-            z = np.load(os.path.join(d, "sample.npz"))
-            assert np.array_equal(z['board'], b) and np.array_equal(z['policy_target'], p) and z['value_target'] == v
+        b, p, v = read_sample(os.path.join(d, "sample.h5"))
         assert b.shape == (1, S, S, 17) and b.dtype == np.float32
         assert p.shape == (S * S + 1,) and p.dtype == np.float32 and v.dtype == np.float32 and v.shape == () and v == 1
     finally:
