@@ -392,22 +392,22 @@ def run_rank(args):
                                                  "flops_per_launch": conv_big_fl,
                                                  "achieved": conv_big_fl * conv_big_n / max(conv_big_ms * 1e-3, 1e-12) / 1e12},
                                "share_of_step_time": conv_ms * 1e-3 / dt}
-            pc = os.path.join(ROOT, "profiles", "r01_pmc_conv.json")
+            pc = os.path.join(ROOT, "profiles", "r02_pmc_conv.json")
             if os.path.isfile(pc) and (S, G, E) == (19, 1024, 8):
                 try:   # HBM bytes per 8192-batch launch: separate --pmc passes; FETCH_SIZE doubled (gfx950 wide-read correction)
                     j = json.load(open(pc))
                     out["roofline"]["traffic"] = (2 * j["FETCH_SIZE"]["mean"] + j["WRITE_SIZE"]["mean"]) * 1024
-                    out["roofline"]["traffic_source"] = ("profiles/r01_pmc_conv.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/convexp/loop8p.py, "
-                                                         "8192 x 17 x 17 launch; algorithmic x + skip + y + weights = 3.63 GB)")
+                    out["roofline"]["traffic_source"] = ("profiles/r02_pmc_conv.json (tools/pmc_conv_traffic.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                                         "passes of this command, 8192-position launches; algorithmic x + skip + y + weights = 3.63 GB with skip, 2.42 GB without)")
                 except Exception:
                     pass
         else:
             out["roofline"] = dict(out["roofline_board_advance"])
-        tr = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.isfile(tr) and (S, G, E) == (19, 1024, 8) and not eng.fused_pack:
+        tr = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json" if eng.fused_pack else "r01_pmc_traffic.json")
+        if os.path.isfile(tr) and (S, G, E) == (19, 1024, 8):
             try:
                 out["roofline_board_advance"]["traffic"] = json.load(open(tr)).get("traffic_bytes_per_launch_corrected")
-                out["roofline_board_advance"]["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
+                out["roofline_board_advance"]["traffic_source"] = "profiles/%s (tools/pmc_bench.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)" % os.path.basename(tr)
             except Exception:
                 pass
         eng.close()
