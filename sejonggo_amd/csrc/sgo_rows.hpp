@@ -211,7 +211,8 @@ SGO_DEV int advance_record_rows(const uint32_t *in, uint32_t *out, int a, bool s
 // lanes 0..NW-1 of the half) and who is to move in the child.
 template <int S>
 struct Board_rows_result {
-    uint32_t w0, w1;
+    uint32_t w0, w1;      // word `lane` of the child's planes 0 / 1
+    uint32_t rb, rw;      // row `lane` of the child's black / white stones
     bool child_white;
 };
 
@@ -237,6 +238,8 @@ SGO_DEV void rows_advance_keep(const uint32_t *in, uint32_t *out, int a, uint32_
     if (y == (G::N >> 5)) wl |= 1u << (G::N & 31);              // pass is always legal
     res.w0 = w0;
     res.w1 = w1;
+    res.rb = nb;
+    res.rw = nw;
     res.child_white = !mover_white;
     if (!out) return;
     if (y < G::NW) {

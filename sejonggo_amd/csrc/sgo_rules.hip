@@ -270,34 +270,42 @@ __global__ __launch_bounds__(64) void k_board_advance_rows_nn(int n, const int *
     // ---- the ply itself (same code path as k_board_advance_rows)
     Board_rows_result<S> r;
     rows_advance_keep<S>(src, live ? dst : nullptr, moves[i], live ? lg : nullptr, half, y, r);
-    // ---- network input row of the child
+    // ---- network input row of the child.  Each lane (board row y) publishes the 16 plane rows of ITS row -- the new pair
+    //      from registers, the history from the parent record -- in the network's relative plane order as one 64-byte LDS
+    //      record [half][row][plane]; a point's eight planes of one output quarter are then two ds_read_b128.
+    __shared__ __attribute__((aligned(16))) uint32_t tab[2][32][16];
     const int flip = r.child_white ? 1 : 0;          // planes relative to the side to move: relative c = absolute c ^ flip
-    _Float16 *orow = nn_out + (size_t)nn_row[i] * G::N * 32;
+    {
+        uint32_t *mine = &tab[half][y][0];
+        mine[0 ^ flip] = r.rb;
+        mine[1 ^ flip] = r.rw;
+#pragma unroll
+        for (int a = 2; a < 16; a++) mine[a ^ flip] = rows::load_row<S>(src + (a - 2) * G::NW, y);   // 0 for padding rows
+    }
+    __syncthreads();
+    char *orow = reinterpret_cast<char *>(nn_out + (size_t)nn_row[i] * G::N * 32);
     const int q = y & 3;
-#pragma unroll 1
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll 2
     for (int p0 = 0; p0 < G::N; p0 += 8) {
         const int pt = p0 + (y >> 2);
         const int pp = pt < G::N ? pt : G::N - 1;
         const int pi = pp / S, pj = pp - pi * S;
         int si, sj;
         sym_src(S, k, pi, pj, si, sj);
-        const int sp = si * S + sj, wi = sp >> 5, sh = sp & 31;
-        // the child's planes 0 / 1 live in lanes 0..NW-1 of this half (word index = lane)
-        const uint32_t nb = (uint32_t)__shfl((int)r.w0, half * 32 + wi, 64), nw = (uint32_t)__shfl((int)r.w1, half * 32 + wi, 64);
-        h8 v;
-#pragma unroll
-        for (int c = 0; c < 8; c++) v[c] = (_Float16)0.0f;
+        u32x4 o = {0u, 0u, 0u, 0u};
         if (q < 2) {
-#pragma unroll
-            for (int c = 0; c < 8; c++) {
-                const int a = (q * 8 + c) ^ flip;    // absolute plane of relative channel q*8 + c
-                const uint32_t word = (a == 0) ? nb : (a == 1) ? nw : src[(a - 2) * G::NW + wi];
-                v[c] = (_Float16)(float)((word >> sh) & 1u);
-            }
+            const u32x4 lo = *reinterpret_cast<const u32x4 *>(&tab[half][si][q * 8]);
+            const u32x4 hi = *reinterpret_cast<const u32x4 *>(&tab[half][si][q * 8 + 4]);
+            // bit sj of plane c -> fp16 1.0 (0x3C00) or 0.0; two planes per dword
+            o[0] = ((lo[0] >> sj) & 1u) * 0x3C00u | ((lo[1] >> sj) & 1u) * 0x3C000000u;
+            o[1] = ((lo[2] >> sj) & 1u) * 0x3C00u | ((lo[3] >> sj) & 1u) * 0x3C000000u;
+            o[2] = ((hi[0] >> sj) & 1u) * 0x3C00u | ((hi[1] >> sj) & 1u) * 0x3C000000u;
+            o[3] = ((hi[2] >> sj) & 1u) * 0x3C00u | ((hi[3] >> sj) & 1u) * 0x3C000000u;
         } else if (q == 2) {
-            v[0] = (_Float16)(flip ? -1.0f : 1.0f);
+            o[0] = flip ? 0xBC00u : 0x3C00u;         // the colour plane: -1.0 / +1.0
         }
-        if (live && pt < G::N) *reinterpret_cast<h8 *>(orow + (size_t)pt * 32 + q * 8) = v;
+        if (live && pt < G::N) *reinterpret_cast<u32x4 *>(orow + (size_t)pt * 64 + q * 16) = o;
     }
 }
 
