@@ -152,7 +152,10 @@ typedef struct sgo_config {
     double komi;              /* conf['KOMI'] */
     double dirichlet_epsilon; /* conf['DIRICHLET_EPSILON'] */
     int32_t device_id;
-    int32_t reserved;
+    int32_t two_model;        /* 1: evaluation games between two nets (evaluate_worker.py:137): one tree per player, the tree of
+                                 the side not to move follows the move when it holds it (nomodel_self_play.py:203-218);
+                                 requires self_play = 0.  Every row of a step's evaluation list belongs to one model:
+                                 sgo_eval_models() */
 } sgo_config;
 
 typedef struct sgo_status {
@@ -185,6 +188,7 @@ typedef struct sgo_game_result {
     int32_t n_moves;
     int32_t last_player; /* 'player' when the loop ended (used for "X+R") */
     int32_t done;
+    int32_t first_model; /* two_model games: which model moved first = plays black (0 = model1, 1 = model2) */
 } sgo_game_result;
 
 sgo_ctx *sgo_ctx_create(const sgo_config *cfg);
@@ -196,6 +200,14 @@ void sgo_ctx_destroy(sgo_ctx *ctx);
  * (use the stream the steps run on): no device-wide synchronisation. */
 int sgo_start_games(sgo_ctx *ctx, int n, const int32_t *slots, const double *noise, const double *uniforms,
                     int n_uniforms, const float *resign, void *stream);
+/* (Re)start slots of a two_model context: no Dirichlet noise (self_play is off), one resign threshold per model
+ * (nomodel_self_play.py:170: `resign_model1 if current == model1 else resign_model2`), and who moves first
+ * (first_model[i] = 0: model1 plays black; play.py:301-306 choose_first_player is the caller's coin). */
+int sgo_start_games2(sgo_ctx *ctx, int n, const int32_t *slots, const double *uniforms, int n_uniforms,
+                     const float *resign_model1, const float *resign_model2, const int32_t *first_model, void *stream);
+/* Which model (0 / 1) must evaluate each row of the evaluation list of the last step (all 0 unless two_model).  HOST buffer
+ * models[cap]; returns the number of rows. */
+int sgo_eval_models(sgo_ctx *ctx, int cap, int32_t *models);
 /* One engine step.  Consumes the evaluations of the positions listed by the previous step
  * (d_policy [n_eval][A] float32, d_value [n_eval] float32, produced from inputs transformed by
  * symmetry sym_k; NULL on the first call), back-propagates, selects the next leaves, plays moves whose

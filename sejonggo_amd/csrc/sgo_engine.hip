@@ -51,6 +51,12 @@ struct GameState {
     double white;
     int32_t n_moves, last_player;
     int64_t n_predict, none_events;
+    // two-model (evaluation) games, nomodel_self_play.py:203-218: the side NOT to move keeps its own tree
+    int32_t cur_model, first_model;       // 0 = model1, 1 = model2: who searches now / who moved first (plays black)
+    int32_t other_root, other_count;      // the other player's tree: root block (-1: none) and root statistics
+    float other_value, other_mean;
+    float resign2;
+    int32_t has_resign2;
 };
 
 struct Counters {
@@ -89,6 +95,7 @@ struct Ctx {
     int32_t *reqBlk, *reqParent, *reqMove;  // [G][E]; block ids are GLOBAL (g*cap + local)
     // compacted lists
     int32_t *evalIdx, *leafIn, *leafMv, *leafOut;  // [G*E]
+    int32_t *evalModel;   // [G*E] which model evaluates each row of the evaluation list (two-model games; 0 otherwise)
     int32_t *leafRow;     // [G*E] row of each leaf in the evaluation list (fused board_advance + nn_input_pack)
     int32_t *rootIdx, *rootRow;  // [G] block id / evaluation row of this step's root requests
     // records
@@ -104,7 +111,7 @@ struct Ctx {
 };
 
 struct StageLayout {  // byte offsets into the staging area for a batch of n restarts (all 8-byte aligned)
-    size_t slots, resign, noise, uniforms, total;
+    size_t slots, resign, resign2, first, noise, uniforms, total;
     int nu;
 };
 static inline size_t al8(size_t v) { return (v + 7) & ~(size_t)7; }
@@ -113,7 +120,9 @@ static StageLayout stage_layout(int n, int APAD, int nu, bool has_noise) {
     L.nu = nu;
     L.slots = 0;
     L.resign = al8(sizeof(int32_t) * (size_t)n);
-    L.noise = L.resign + al8(sizeof(float) * (size_t)n);
+    L.resign2 = L.resign + al8(sizeof(float) * (size_t)n);
+    L.first = L.resign2 + al8(sizeof(float) * (size_t)n);
+    L.noise = L.first + al8(sizeof(int32_t) * (size_t)n);
     L.uniforms = L.noise + (has_noise ? sizeof(double) * (size_t)n * APAD : 0);
     L.total = L.uniforms + sizeof(double) * (size_t)n * nu;
     return L;
@@ -364,7 +373,9 @@ __global__ __launch_bounds__(64) void k_search(Ctx c, const float *policy, const
             st.has_value = 1;
             st.n_predict++;
             if (lane == 0) atomicAdd(&c.counters->total_evals, 1ull);
-            if (st.has_resign && st.value <= st.resign) {
+            // resign = resign_model1 if current == model1 else resign_model2 (nomodel_self_play.py:170-173)
+            const bool use2 = c.cfg.two_model && st.cur_model == 1;
+            if (use2 ? (st.has_resign2 && st.value <= st.resign2) : (st.has_resign && st.value <= st.resign)) {
                 finish(1);
             } else {
                 // "if not mcts_tree or not mcts_tree['subtree']": the root block carries children iff flag set
@@ -498,14 +509,32 @@ __global__ __launch_bounds__(64) void k_search(Ctx c, const float *policy, const
             st.root_value = __shfl(rv, selected & 63);
             st.root_mean = __shfl(rm, selected & 63);
             const int mover = white_to_play<S>(c.pos + (e.gb0 + st.root_blk) * G::RW) ? -1 : 1;
+            // Two-model games (self_play == False, nomodel_self_play.py:203-208): the other player's tree follows the move when
+            // it holds it ("if other_mcts and index in other_mcts['subtree']"); a child that was never evaluated there has an
+            // empty subtree, i.e. the tree is rebuilt by new_tree() when its owner moves next -- here: no block, onr stays -1.
+            int onr = -1;
+            if (c.cfg.two_model && st.other_root >= 0 && c.bSlot[e.gb0 + st.other_root] != -2) {
+                const size_t osb = e.slot_base(st.other_root);
+                int ocb = -1, oc = 0; float ov = 0, om = 0;
+                if (lane == (selected & 63) && e.legal_bit(st.other_root, selected)) {
+                    ocb = c.cB[osb + selected]; oc = c.cN[osb + selected]; ov = c.cW[osb + selected]; om = c.cQ[osb + selected];
+                }
+                onr = __shfl(ocb, selected & 63);
+                st.other_count = __shfl(oc, selected & 63);
+                st.other_value = __shfl(ov, selected & 63);
+                st.other_mean = __shfl(om, selected & 63);
+            }
             st.root_blk = nr;
             st.root_f64 = 0;
-            if (lane == 0) { c.bParent[e.gb0 + nr] = -1; c.bSlot[e.gb0 + nr] = -1; }
-            // mark: BFS over expanded nodes
+            if (lane == 0) {
+                c.bParent[e.gb0 + nr] = -1; c.bSlot[e.gb0 + nr] = -1;
+                if (onr >= 0) { c.bParent[e.gb0 + onr] = -1; c.bSlot[e.gb0 + onr] = -1; }
+            }
+            // mark: BFS over expanded nodes (of both trees)
             for (int i = lane; i < (c.cap + 31) / 32; i += 64) marks[i] = 0;
-            if (lane == 0) queue[0] = nr;
+            if (lane == 0) { queue[0] = nr; if (onr >= 0) queue[1] = onr; }
             __syncthreads();
-            int head = 0, tail = 1;
+            int head = 0, tail = onr >= 0 ? 2 : 1;
             while (head < tail) {
                 const int b = queue[head++];
                 const size_t bsb = e.slot_base(b);
@@ -530,6 +559,25 @@ __global__ __launch_bounds__(64) void k_search(Ctx c, const float *policy, const
             }
             st.free_top = ft;
             __syncthreads();
+            if (c.cfg.two_model) {
+                if (onr < 0) {
+                    // the other player's tree is empty: a fresh root block holding the position after the move (a copy of the
+                    // mover's new root), unexpanded -- new_tree() fills it when that player's root evaluation arrives
+                    if (st.free_top <= 0) { fail(SGO_ERR_CAPACITY); break; }
+                    onr = c.freeList[(size_t)g * c.cap + st.free_top - 1];
+                    st.free_top--;
+                    for (int i = lane; i < G::RW; i += 64) c.pos[(e.gb0 + onr) * G::RW + i] = c.pos[(e.gb0 + nr) * G::RW + i];
+                    for (int i = lane; i < G::NW; i += 64) c.legal[(e.gb0 + onr) * G::NW + i] = c.legal[(e.gb0 + nr) * G::NW + i];
+                    if (lane == 0) { c.bParent[e.gb0 + onr] = -1; c.bSlot[e.gb0 + onr] = -2; }
+                    st.other_count = 0; st.other_value = 0.f; st.other_mean = 0.f;
+                    __syncthreads();
+                }
+                // mcts_tree, other_mcts = other_mcts, mcts_tree (:218) and the models swap (:217)
+                const int tb = st.root_blk, tc = st.root_count; const float tv = st.root_value, tm = st.root_mean;
+                st.root_blk = onr; st.root_count = st.other_count; st.root_value = st.other_value; st.root_mean = st.other_mean;
+                st.other_root = tb; st.other_count = tc; st.other_value = tv; st.other_mean = tm;
+                st.cur_model ^= 1;
+            }
             // board, player = make_play(...): the new root block already holds the position after the move
             st.player = mover;
             st.move_n++;
@@ -638,6 +686,7 @@ __global__ __launch_bounds__(1024) void k_compact(Ctx c) {
         s.eval_base = be;
         for (int j = 0; j < s.n_req; j++) {
             c.evalIdx[be + j] = c.reqBlk[(size_t)g * c.E + j];
+            c.evalModel[be + j] = s.cur_model;
             if (s.req_kind == 1) {
                 c.leafIn[bl + j] = c.reqParent[(size_t)g * c.E + j];
                 c.leafMv[bl + j] = c.reqMove[(size_t)g * c.E + j];
@@ -699,6 +748,12 @@ __global__ __launch_bounds__(64) void k_start(Ctx c, int n, StageLayout L, int h
     float r = resign[k];
     st.has_resign = !(r != r) && r != 0.f;   // `if resign and ...` (nomodel_self_play.py:171): None and 0.0 never resign
     st.resign = st.has_resign ? r : 0.f;
+    const float r2 = reinterpret_cast<const float *>(c.stage + L.resign2)[k];
+    st.has_resign2 = !(r2 != r2) && r2 != 0.f;
+    st.resign2 = st.has_resign2 ? r2 : 0.f;
+    st.first_model = c.cfg.two_model ? (reinterpret_cast<const int32_t *>(c.stage + L.first)[k] & 1) : 0;
+    st.cur_model = st.first_model;
+    st.other_root = -1;
     if (c.max_moves == 0) st.phase = PH_DONE;
     for (int i = lane; i < G::RW; i += 64) c.pos[gb0 * G::RW + i] = 0;
     for (int i = lane; i < G::NW; i += 64) {
@@ -778,6 +833,7 @@ static int ctx_alloc(Ctx &c) {
     CK(dalloc(&c.leafMv, nr));
     CK(dalloc(&c.leafOut, nr));
     CK(dalloc(&c.leafRow, nr));
+    CK(dalloc(&c.evalModel, nr));
     CK(dalloc(&c.rootIdx, nr));
     CK(dalloc(&c.rootRow, nr));
     CK(dalloc(&c.recs, (size_t)c.rec_cap));
@@ -801,7 +857,7 @@ static int ctx_alloc(Ctx &c) {
 static void ctx_free(Ctx &c) {
     void *ptrs[] = {c.gs, c.pos, c.legal, c.cP, c.cW, c.cQ, c.cN, c.cB, c.cBusy, c.bParent, c.bSlot, c.freeList,
                     c.rootP64, c.noise, c.uniforms, c.fParent, c.fSlot, c.fBlk, c.fEvalLocal, c.fEvaluated, c.fValue,
-                    c.reqBlk, c.reqParent, c.reqMove, c.evalIdx, c.leafIn, c.leafMv, c.leafOut, c.leafRow, c.rootIdx, c.rootRow, c.recs, c.recPacked,
+                    c.reqBlk, c.reqParent, c.reqMove, c.evalIdx, c.leafIn, c.leafMv, c.leafOut, c.leafRow, c.evalModel, c.rootIdx, c.rootRow, c.recs, c.recPacked,
                     c.recPolicy, c.counters, c.dstatus, c.symLut, c.stage};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -820,6 +876,7 @@ sgo_ctx *sgo_ctx_create(const sgo_config *cfg) {
     Ctx &c = x->c;
     memset((void *)&c.cfg, 0, sizeof c.cfg);
     c.cfg = *cfg;
+    if (c.cfg.two_model && c.cfg.self_play) { set_error("sgo_ctx_create: two_model games are not self-play games"); delete x; return nullptr; }
     c.S = cfg->size; c.A = c.S * c.S + 1; c.NW = sgo_plane_words(c.S); c.RW = sgo_packed_words(c.S);
     c.APAD = 32 * c.NW; c.G = cfg->n_games; c.E = cfg->energy;
     c.cap = cfg->blocks_per_game > 0 ? cfg->blocks_per_game : 10 * cfg->sims + 64;
@@ -857,8 +914,22 @@ void sgo_ctx_destroy(sgo_ctx *x) {
     delete x;
 }
 
+static int start_games_impl(sgo_ctx *x, int n, const int32_t *slots, const double *noise, const double *uniforms, int n_uniforms,
+                            const float *resign, const float *resign2, const int32_t *first_model, void *stream);
+
 int sgo_start_games(sgo_ctx *x, int n, const int32_t *slots, const double *noise, const double *uniforms, int n_uniforms,
                     const float *resign, void *stream) {
+    return start_games_impl(x, n, slots, noise, uniforms, n_uniforms, resign, nullptr, nullptr, stream);
+}
+
+int sgo_start_games2(sgo_ctx *x, int n, const int32_t *slots, const double *uniforms, int n_uniforms, const float *resign_model1,
+                     const float *resign_model2, const int32_t *first_model, void *stream) {
+    if (!x || !x->c.cfg.two_model) { set_error("sgo_start_games2: the context was not created with two_model = 1"); return SGO_ERR_STATE; }
+    return start_games_impl(x, n, slots, nullptr, uniforms, n_uniforms, resign_model1, resign_model2, first_model, stream);
+}
+
+static int start_games_impl(sgo_ctx *x, int n, const int32_t *slots, const double *noise, const double *uniforms, int n_uniforms,
+                            const float *resign, const float *resign2, const int32_t *first_model, void *stream) {
     if (!x || n < 0 || (n && !slots)) { set_error("sgo_start_games: bad argument"); return SGO_ERR_ARG; }
     Ctx &c = x->c;
     if (n == 0) return SGO_OK;
@@ -873,8 +944,13 @@ int sgo_start_games(sgo_ctx *x, int n, const int32_t *slots, const double *noise
     const StageLayout L = stage_layout(n, c.APAD, nu, noise != nullptr);
     uint8_t *h = x->h.stage;
     memcpy(h + L.slots, slots, sizeof(int32_t) * n);
-    float *hr = reinterpret_cast<float *>(h + L.resign);
-    for (int i = 0; i < n; i++) hr[i] = resign ? resign[i] : NAN;
+    float *hr = reinterpret_cast<float *>(h + L.resign), *hr2 = reinterpret_cast<float *>(h + L.resign2);
+    int32_t *hf = reinterpret_cast<int32_t *>(h + L.first);
+    for (int i = 0; i < n; i++) {
+        hr[i] = resign ? resign[i] : NAN;
+        hr2[i] = resign2 ? resign2[i] : NAN;
+        hf[i] = first_model ? first_model[i] : 0;
+    }
     if (noise) {
         double *hn = reinterpret_cast<double *>(h + L.noise);
         for (int i = 0; i < n; i++) {
@@ -962,6 +1038,18 @@ static int step_impl(sgo_ctx *x, const float *d_policy, const float *d_value, in
     return SGO_OK;
 }
 
+int sgo_eval_models(sgo_ctx *x, int cap, int32_t *models) {
+    if (!x || !models || cap < 0) { set_error("sgo_eval_models: bad argument"); return SGO_ERR_ARG; }
+    Ctx &c = x->c;
+    const int n = c.last_n_eval;
+    if (n > cap) { set_error("sgo_eval_models: caller buffer too small"); return SGO_ERR_ARG; }
+    if (n > 0) {
+        SGO_HIP(hipMemcpyAsync(models, c.evalModel, sizeof(int32_t) * n, hipMemcpyDeviceToHost, x->h.last_stream));
+        SGO_HIP(hipStreamSynchronize(x->h.last_stream));
+    }
+    return n;
+}
+
 int sgo_collect(sgo_ctx *x, int sym_k, int layout, int dtype, void *d_nn_in, void *stream) {
     if (!x || !d_nn_in) { set_error("sgo_collect: bad argument"); return SGO_ERR_ARG; }
     Ctx &c = x->c;
@@ -1001,6 +1089,7 @@ int sgo_game_results(sgo_ctx *x, int n, const int32_t *slots, sgo_game_result *o
         const GameState &s = all[g];
         out[i].winner = s.winner; out[i].black = s.black; out[i].white = s.white; out[i].end_reason = s.end_reason;
         out[i].n_moves = s.n_moves; out[i].last_player = s.last_player; out[i].done = (s.phase == PH_DONE) ? 1 : 0;
+        out[i].first_model = s.first_model;
         if (s.error) out[i].done = s.error;
     }
     return SGO_OK;

@@ -58,11 +58,18 @@ class MoveRecord(dict):
 class SelfPlayEngine(object):
     def __init__(self, net, size=None, n_games=None, sims=None, energy=None, stop_exploration=None, num_moves=None,
                  komi=None, self_play=True, dirichlet_alpha=None, dirichlet_epsilon=None, blocks_per_game=0,
-                 device=0, symmetry="random1", layout="nhwc", dtype="fp16", seed=0, raise_on_error=True, fused_pack=True):
+                 device=0, symmetry="random1", layout="nhwc", dtype="fp16", seed=0, raise_on_error=True, fused_pack=True,
+                 net2=None):
+        """net2: a second net turns the slots into two-model EVALUATION games (evaluate_worker.py:137: model1 = `net`,
+        model2 = `net2`, one tree per player, no Dirichlet noise); start them with start_eval_games."""
         import torch
         self.torch = torch
         self.lib = _lib.require_gpu()
         self.net = net
+        self.net2 = net2
+        self.two_model = net2 is not None
+        if self.two_model:
+            self_play = False
         self.S = size or conf['SIZE']
         self.A = self.S * self.S + 1
         self.G = n_games or conf['GAMES_PER_GPU']
@@ -85,7 +92,7 @@ class SelfPlayEngine(object):
                           stop_exploration=self.stop_exploration, num_moves=-1 if num_moves is None else num_moves,
                           blocks_per_game=blocks_per_game, self_play=1 if self_play else 0, komi=self.komi,
                           dirichlet_epsilon=conf['DIRICHLET_EPSILON'] if dirichlet_epsilon is None else dirichlet_epsilon,
-                          device_id=device, reserved=0)
+                          device_id=device, two_model=1 if self.two_model else 0)
         self.ctx = C.c_void_p(self.lib.sgo_ctx_create(C.byref(cfg)))
         if not self.ctx:
             raise _lib.SgoError("sgo_ctx_create failed: %s" % self.lib.sgo_last_error().decode())
@@ -105,6 +112,7 @@ class SelfPlayEngine(object):
         self.n_steps = 0
         self.n_net_calls = 0
         self.n_net_positions = 0
+        self.n_model_positions = [0, 0]    # two-model games: positions evaluated by model1 / model2
         self._primed = False
         # nn_input_pack fused into board_advance (sgo_step_fused): the step that lists positions also writes their network
         # input, for the fused net's layout (fp16 NHWC-32) and one symmetry per batch
@@ -148,6 +156,33 @@ class SelfPlayEngine(object):
             self.records[int(s)] = []
             self.game_ids[int(s)] = None if ids is None else ids[i]
 
+    def start_eval_games(self, slots, first_model=None, uniforms=None, resign_model1=None, resign_model2=None, ids=None):
+        """(Re)start two-model game slots.  first_model[i] = 0: model1 moves first (plays black).  Default: the reference's
+        coin, play.choose_first_player (one draw of Python's `random` per game, model1 first below .5)."""
+        from . import play
+        slots = np.ascontiguousarray(slots, dtype=np.int32)
+        n = len(slots)
+        if n == 0:
+            return
+        if first_model is None:
+            first_model = [0 if play.choose_first_player(0, 1)[0] == 0 else 1 for _ in range(n)]
+        first_model = np.ascontiguousarray(first_model, dtype=np.int32)
+        if uniforms is None:
+            uniforms = self.rng.random_sample((n, max(1, self.max_moves)))
+        uniforms = np.ascontiguousarray(uniforms, dtype=np.float64).reshape(n, -1)
+
+        def thr(r):
+            if r is None:
+                return None
+            return np.array([np.nan if not v else v for v in (r if np.ndim(r) else [r] * n)], dtype=np.float32)
+
+        r1, r2 = thr(resign_model1), thr(resign_model2)
+        _lib.check(self.lib.sgo_start_games2(self.ctx, C.c_int(n), _lib.ptr(slots), _lib.ptr(uniforms), C.c_int(uniforms.shape[1]),
+                                             _lib.ptr(r1), _lib.ptr(r2), _lib.ptr(first_model), _lib.stream_ptr()), "sgo_start_games2")
+        for i, s in enumerate(slots):
+            self.records[int(s)] = []
+            self.game_ids[int(s)] = None if ids is None else ids[i]
+
     # ------------------------------------------------------------------ one engine step
     def _lut(self, k):
         torch = self.torch
@@ -171,10 +206,31 @@ class SelfPlayEngine(object):
         x = self.nn_in[:n]
         if self.layout == 1:
             x = x.permute(0, 2, 3, 1)  # present the reference's NHWC view
-        p, v = self.net.predict_on_batch(x)
         self.n_net_calls += 1
         self.n_net_positions += n
-        return p.to(torch.float32), v.to(torch.float32).reshape(n)
+        if not self.two_model:
+            p, v = self.net.predict_on_batch(x)
+            return p.to(torch.float32), v.to(torch.float32).reshape(n)
+        # two-model games: every row of the list belongs to the model that is to move in its game
+        ids = np.zeros(n, dtype=np.int32)
+        _lib.check(self.lib.sgo_eval_models(self.ctx, C.c_int(n), _lib.ptr(ids)), "sgo_eval_models")
+        pol = torch.empty((n, self.A), dtype=torch.float32, device=self.device)
+        val = torch.empty((n,), dtype=torch.float32, device=self.device)
+        for m, net in ((0, self.net), (1, self.net2)):
+            idx = np.flatnonzero(ids == m)
+            if len(idx) == 0:
+                continue
+            self.n_model_positions[m] += len(idx)
+            if len(idx) == n:
+                p, v = net.predict_on_batch(x)
+                pol.copy_(p)
+                val.copy_(v.reshape(n))
+                continue
+            it = torch.from_numpy(idx).to(self.device)
+            p, v = net.predict_on_batch(x.index_select(0, it).contiguous())
+            pol.index_copy_(0, it, p.to(torch.float32))
+            val.index_copy_(0, it, v.to(torch.float32).reshape(-1))
+        return pol, val
 
     def step(self):
         """One engine step; returns the status struct."""
@@ -258,6 +314,8 @@ class SelfPlayEngine(object):
 
     def game_data(self, slot, result, model_name=None):
         """The reference's game_data dict (nomodel_self_play.py:261-270) for a finished slot."""
+        if self.two_model:
+            return self._eval_game_data(slot, result)
         name = model_name or getattr(self.net, "name", "model")
         winner = int(result["winner"])
         player_string = {1: "B", 0: "D", -1: "W"}
@@ -275,6 +333,34 @@ class SelfPlayEngine(object):
             'end_reason': END_REASONS[int(result["end_reason"])],
             'black_points': int(result["black"]), 'white_points': float(result["white"]),
             'slot': int(slot), 'id': self.game_ids.get(int(slot)),
+        }
+
+    def _eval_game_data(self, slot, result):
+        """game_data of a two-model game (nomodel_self_play.py:227-270): model names by colour, winner_model with the
+        reference's rule -- right while model1 plays black, the loser's name otherwise (:247) -- behind COMPAT_WINNER_MODEL."""
+        names = (getattr(self.net, "name", "model1"), getattr(self.net2, "name", "model2"))
+        model1_black = int(result["first_model"]) == 0
+        nameB, nameW = (names[0], names[1]) if model1_black else (names[1], names[0])
+        winner = int(result["winner"])
+        tag = {1: "B", 0: "D", -1: "W"}
+        if int(result["end_reason"]) == 1:
+            winner_string = "%s+R" % tag[int(result["last_player"])]
+        else:
+            winner_string = "%s+%s" % (tag[winner], abs(int(result["black"]) - float(result["white"])))
+        if winner == 0:
+            winner_model = None
+        elif conf.get('COMPAT_WINNER_MODEL', True):
+            winner_model = nameB if (winner == 1) == model1_black else nameW
+        else:
+            winner_model = nameB if winner == 1 else nameW
+        return {
+            'moves': self.records.get(int(slot), []),
+            'modelB_name': nameB, 'modelW_name': nameW,
+            'winner': {1: 1, -1: 0, 0: None}[winner], 'winner_model': winner_model, 'result': winner_string,
+            'resign_model1': None, 'resign_model2': None,
+            'end_reason': END_REASONS[int(result["end_reason"])],
+            'black_points': int(result["black"]), 'white_points': float(result["white"]),
+            'slot': int(slot), 'id': self.game_ids.get(int(slot)), 'first_model': int(result["first_model"]),
         }
 
     def run(self, max_steps=None):

@@ -37,12 +37,36 @@ def test_geometry_and_errors():
     assert lib.sgo_plane_words(8) < 0  # unsupported size is an error, not a fallback
 
 
-def test_struct_layouts_match_header():
+def test_struct_layouts_match_header(tmp_path):
+    """ctypes structs / numpy dtypes of _lib.py against the C compiler's view of include/sgo.h: sizes and every field offset."""
+    import os
+    import subprocess
     L = _lib()
     assert ctypes.sizeof(L.Config) == 56
     assert ctypes.sizeof(L.Status) == 48
     assert ctypes.sizeof(L.MoveRecord) == 24 == L.MOVE_RECORD_DTYPE.itemsize
-    assert ctypes.sizeof(L.GameResult) == 32 == L.GAME_RESULT_DTYPE.itemsize
+    assert ctypes.sizeof(L.GameResult) == 40 == L.GAME_RESULT_DTYPE.itemsize
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    structs = {"sgo_config": L.Config, "sgo_status": L.Status, "sgo_move_record": L.MoveRecord, "sgo_game_result": L.GameResult}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "sgo.h"', 'int main(void) {']
+    for cname, cls in structs.items():
+        lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in cls._fields_:
+            lines.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    lines += ['return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = str(tmp_path / "layout")
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(root, "include"), str(src), "-o", exe])
+    got = dict(l.split() for l in subprocess.check_output([exe], text=True).splitlines())
+    for cname, cls in structs.items():
+        assert int(got[cname]) == ctypes.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(got["%s.%s" % (cname, fname)]) == getattr(cls, fname).offset, (cname, fname)
+    for name in L.GAME_RESULT_DTYPE.names:
+        assert L.GAME_RESULT_DTYPE.fields[name][1] == getattr(L.GameResult, name).offset
+    for name in L.MOVE_RECORD_DTYPE.names:
+        assert L.MOVE_RECORD_DTYPE.fields[name][1] == getattr(L.MoveRecord, name).offset
 
 
 def test_sym_lut_is_host_side_and_matches_golden():

@@ -349,3 +349,42 @@ def test_promote_best_model(tmp_path):
         assert os.listdir(conf['EVAL_DIR']) == []
     finally:
         _restore(conf, old)
+
+
+@pytest.mark.gpu
+def test_evaluation_worker_on_the_device(tmp_path):
+    """evaluate_worker.NoModelEvaluateWorker's body: best vs latest as concurrent two-model slots of the device engine, eval
+    games saved as training data + one result file per game, then the 55 % gate (evaluator.py:50-80)."""
+    import torch
+    from sejonggo_amd import evaluator as ev, model as M, predicting_queue_worker as pq
+    from sejonggo_amd.evaluate_worker import run_evaluation
+    conf, old = _with_conf(tmp_path, SIZE=9, N_RESIDUAL_BLOCKS=1, NET_CHANNELS=32, MCTS_SIMULATIONS=16, ENERGY=8, GPUs=[0],
+                           EVALUATE_N_GAMES=6, GAMES_PER_GPU=4, COMPAT_LATEST_SYM=False, EVALUATE_MARGIN=.55)
+    try:
+        os.makedirs(conf['MODEL_DIR']); os.makedirs(conf['EVAL_DIR'])
+        torch.manual_seed(1)
+        M.save_model(M.PolicyValueNet(9, 1, 32, name="model_1"), "best_model")
+        M.save_model(M.PolicyValueNet(9, 1, 32, name="model_1"), "model_1")
+        torch.manual_seed(2)
+        M.save_model(M.PolicyValueNet(9, 1, 32, name="model_2"), "model_2")
+        pq.set_model_factory(None)
+        wins, total = run_evaluation(0, engine_kwargs={"num_moves": 30})
+        assert total == 6 and 0 <= wins <= 6
+        stat = ev.eval_statistic()
+        assert set(stat) == {"model_2"} and abs(stat["model_2"] - wins / 6.0) < 1e-9
+        for g in range(6):
+            d = os.path.join(conf['EVAL_DIR'], "model_2", "game_%03d" % g)
+            names = os.listdir(d)
+            assert len(names) == 1 and names[0] in ("model_1", "model_2", "None")
+            assert os.path.isfile(os.path.join(conf['GAMES_DIR'], "model_2", "eval_game_%03d" % g, "move_000", "sample.h5"))
+        promoted = ev.promote_best_model()
+        assert promoted == (wins / 6.0 > .55)
+        assert M.load_best_model().name == ("model_2" if promoted else "model_1")
+        # best == latest: the worker quits like the reference (evaluate_worker.py:153-154)
+        os.remove(os.path.join(conf['MODEL_DIR'], "model_2.pt"))
+        pq.destroy_predicting_workers([0])
+        if not promoted:
+            assert run_evaluation(0) == (0, 0)
+    finally:
+        pq.destroy_predicting_workers([0])
+        _restore(conf, old)

@@ -185,6 +185,92 @@ def test_headline_batch_shape_equals_the_oracle_on_sampled_slots(L):
     eng.close()
 
 
+TWO_MODEL_FILES = ["async_09.npz", "async_10.npz", "async_11.npz"]
+
+
+def _eval_engine(z, halt_at=None):
+    from sejonggo_amd.engine import SelfPlayEngine
+    from sejonggo_amd.stub_nets import make_stub
+    from tests.helpers import name_of
+    S, nm = int(z["size"]), int(z["num_moves"])
+    kinds = name_of(z, "net").split("+")
+    eng = SelfPlayEngine(make_stub(kinds[0], S), net2=make_stub(kinds[1], S), size=S, n_games=1, sims=int(z["sims"]),
+                         energy=int(z["energy"]), stop_exploration=int(z["stop_exploration"]), num_moves=None if nm < 0 else nm,
+                         komi=float(z["komi"]), symmetry="identity")
+    eng.start_eval_games([0], first_model=[0 if float(z["first_draw"]) < .5 else 1])
+    if halt_at is not None:
+        eng.set_halt(0, halt_at)
+    return eng
+
+
+@pytest.mark.parametrize("fn", TWO_MODEL_FILES)
+def test_two_model_games_on_the_device_equal_the_reference(L, fn):
+    """Evaluation games (evaluate_worker.py:137) inside k_search: two root pointers per slot, the tree of the side not to
+    move follows the move when it holds it, each evaluation row tagged with the model that is to move.  Against the
+    reference's two-model goldens: every move, value, policy target and position, the searching player's whole tree after
+    selected moves, evaluations per model, result, colours and winner_model (incl. the reference's slip when model1 is white)."""
+    from tests.helpers import name_of
+    z = load(fn)
+    S = int(z["size"])
+    eng = _eval_engine(z)
+    games = eng.run()
+    assert len(games) == 1
+    gd = games[0]
+    n_moves = len(z["move_index"])
+    assert len(gd["moves"]) == n_moves
+    for i, mv in enumerate(gd["moves"]):
+        a = mv["move"][0] + S * mv["move"][1] if mv["move"][1] != S else S * S
+        assert a == z["move_index"][i] and mv["player"] == z["move_player"][i], i
+        assert mv["value"].tobytes() == z["move_value"][i].tobytes(), i
+        assert mv["policy"].tobytes() == z["move_policy"][i].tobytes(), i
+        assert np.array_equal(sha8(mv["board"]), z["move_board_hash"][i]), i
+    assert gd["result"] == name_of(z, "result")
+    assert (-99 if gd["winner"] is None else gd["winner"]) == int(z["winner"])
+    assert gd["modelB_name"] == name_of(z, "modelB_name") and gd["modelW_name"] == name_of(z, "modelW_name")
+    assert (gd["winner_model"] or "") == name_of(z, "winner_model")
+    assert eng.n_model_positions == [int(z["n_predict_best"]), int(z["n_predict_latest"])]
+    assert eng.status.total_evals == int(z["n_predict"]) and eng.status.none_events == int(z["none_events"])
+    eng.close()
+    for k in sorted(set([0, 1, 2, 3, n_moves // 2, n_moves - 2, n_moves - 1])):
+        eng = _eval_engine(z, halt_at=k)
+        eng.run()
+        t = eng.root_table(0)
+        assert np.array_equal(t["N"], z["pm_N"][k]) and t["W"].tobytes() == z["pm_W"][k].tobytes(), k
+        assert t["Q"].tobytes() == z["pm_Q"][k].tobytes() and t["P"].tobytes() == z["pm_P"][k].tobytes(), k
+        assert t["root_count"] == z["pm_root_count"][k] and t["root_value"].tobytes() == z["pm_root_value"][k].tobytes(), k
+        buf, nn, ne = eng.tree_serialize(0)
+        assert nn == z["pm_n_nodes"][k] and ne == z["pm_n_expanded"][k], k
+        assert hashlib.sha1(buf.tobytes()).digest()[:16] == z["pm_tree_hash"][k].tobytes(), k
+        eng.close()
+
+
+def test_many_two_model_games_share_a_context(L):
+    """32 concurrent evaluation games with both colour assignments in one context: every game equals the single-game run
+    with the same first player (games do not interact), and both nets see roughly half of the positions."""
+    from sejonggo_amd.engine import SelfPlayEngine
+    from sejonggo_amd.stub_nets import make_stub
+    S, sims, E, nm, G = 9, 32, 8, 12, 32
+    a, b = make_stub("hash", S), make_stub("hash2", S)
+    first = [g % 2 for g in range(G)]
+    eng = SelfPlayEngine(a, net2=b, size=S, n_games=G, sims=sims, energy=E, stop_exploration=0, num_moves=nm, symmetry="identity")
+    eng.start_eval_games(np.arange(G), first_model=first)
+    games = {gd["slot"]: gd for gd in eng.run()}
+    assert len(games) == G and sum(eng.n_model_positions) == eng.status.total_evals
+    assert abs(eng.n_model_positions[0] - eng.n_model_positions[1]) <= G * (sims + 1)
+    eng.close()
+    ref = {}
+    for f in (0, 1):
+        e1 = SelfPlayEngine(a, net2=b, size=S, n_games=1, sims=sims, energy=E, stop_exploration=0, num_moves=nm, symmetry="identity")
+        e1.start_eval_games([0], first_model=[f])
+        ref[f] = e1.run()[0]
+        e1.close()
+    for g in range(G):
+        r = ref[first[g]]
+        assert [m["action"] for m in games[g]["moves"]] == [m["action"] for m in r["moves"]], g
+        assert games[g]["result"] == r["result"] and games[g]["modelB_name"] == r["modelB_name"]
+        assert games[g]["modelB_name"] == ("hash_stub" if first[g] == 0 else "hash_stub_2")
+
+
 class _SymNet(object):
     """Oracle-side wrapper: evaluates the stub through symmetry k exactly like random_symmetry_predict
     (symmetry.py:127-132), or the 8-fold average (build extension)."""
