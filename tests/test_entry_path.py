@@ -388,3 +388,10 @@ def test_evaluation_worker_on_the_device(tmp_path):
     finally:
         pq.destroy_predicting_workers([0])
         _restore(conf, old)
+
+
+@pytest.mark.gpu
+def test_driver_smoke_entry():
+    """__graft_entry__.smoke() -- what the driver runs before the bench -- stays runnable."""
+    import __graft_entry__ as g
+    g.smoke()
