@@ -816,6 +816,92 @@ def child_units(out):
         res.testsRun, len(calls), by, len(sims), len(trees)))
 
 
+GTP_SCRIPT = ["protocol_version", "boardsize 9", "komi 5.5", "clear_board", "play B E5", "genmove W", "genmove B", "play W C3",
+              "genmove B", "play W pass", "genmove B", "genmove W", "play B A9", "genmove W", "genmove B", "genmove W", "play B J1",
+              "genmove W"]
+
+
+def child_gtp(out):
+    """The reference's GTP front-end (sejonggo_nomodel.py:20-160: SejongGoEngine.play / genmove on a persistent tree, GTPEngine's
+    text layer) driven by a command script with the rounding-free stub net; temperature 0 and no noise, so the session is
+    deterministic.  Recorded per command: the reply, the board hash, and (after a genmove) the hash of the kept subtree."""
+    import copy
+    import collections
+    import numpy as np
+    conf = _setup_reference(9, 48, 8)
+    conf["GPUs"] = [0]
+    import play
+    import predicting_queue_worker as pq
+    import simulation_workers as sw
+    import nomodel_self_play as ns
+    from sejonggo_amd.stub_nets import make_stub
+    net = make_stub("hash", 9)
+    counters = {"predict": 0}
+
+    def stub_predict(indicator, board, response_now=False):
+        counters["predict"] += 1
+        p, v = net.predict_on_batch(np.asarray(board))
+        return p[0], v[0][0]
+
+    for m in (pq, sw, ns):
+        m.put_predict_request = stub_predict
+        m.put_name_request = lambda ind: net.name
+    pq.init_predicting_workers = lambda gpus: None
+    pq.destroy_predicting_workers = lambda *a: None
+
+    class FakePool(object):
+        def apply_async(self, fn, args, error_callback=None, callback=None):
+            leaf, board, moves, ind, orig, pid = args
+            fn(copy.deepcopy(leaf), np.copy(board), list(moves), ind, orig, pid)
+
+        def close(self):
+            pass
+
+        def join(self):
+            pass
+
+    class FakeQueue(object):
+        def __init__(self):
+            self.q = collections.deque()
+
+        def put(self, x):
+            self.q.append(x)
+
+        def get(self):
+            return self.q.popleft()
+
+    sw.init_simulation_workers_by_gpuid = lambda gpu: None
+    sw.process_pool = FakePool()
+    sw.simulation_result_queue[0] = FakeQueue()
+    import io
+    import contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        import sejonggo_nomodel as sn
+        sn.put_predict_request = stub_predict
+        eng = sn.GTPEngine()
+    replies, hashes, tree_hashes, n_nodes, players = [], [], [], [], []
+    for cmd in GTP_SCRIPT:
+        with contextlib.redirect_stdout(io.StringIO()):
+            r = eng.parse_command(cmd)
+        replies.append(r)
+        hashes.append(_sha8(eng.sejong_engine.board))
+        t = eng.sejong_engine.mcts_tree
+        if cmd.startswith("genmove") and t is not None and t["subtree"]:
+            h, nn, _ = _tree_hash(t)
+        else:
+            h, nn = b"\0" * 16, 0 if (t is None or not t["subtree"]) else -1
+        tree_hashes.append(np.frombuffer(h, dtype=np.uint8))
+        n_nodes.append(nn)
+        players.append(int(eng.sejong_engine.board[0, 0, 0, -1]))
+    np.savez_compressed(out, size=np.array(9), sims=np.array(48), energy=np.array(8), komi=np.array(5.5),
+                        script=np.frombuffer("\n".join(GTP_SCRIPT).encode(), dtype=np.uint8),
+                        replies=np.frombuffer("\x1e".join(replies).encode(), dtype=np.uint8),
+                        board_hash=np.array(hashes, dtype=np.uint8), tree_hash=np.array(tree_hashes, dtype=np.uint8),
+                        n_nodes=np.array(n_nodes, dtype=np.int64), to_play=np.array(players, dtype=np.int8),
+                        n_predict=np.array(counters["predict"]), version=np.frombuffer(eng.version().encode(), dtype=np.uint8))
+    print("gtp: %d commands, replies %s, %d predicts" % (len(GTP_SCRIPT), [r.strip() for r in replies], counters["predict"]))
+
+
 # ----------------------------------------------------------------------------------------------
 # parent side
 # ----------------------------------------------------------------------------------------------
@@ -870,6 +956,8 @@ def main():
             child_puct(a.child[1])
         elif what == "units":
             child_units(a.child[1])
+        elif what == "gtp":
+            child_gtp(a.child[1])
         elif what == "sync":
             s_, sims, b, net, nm, se, seed, out = a.child[1:]
             child_sync(int(s_), int(sims), int(b), net, int(nm), int(se), int(seed), out)
@@ -891,6 +979,8 @@ def main():
         run_child(["puct", os.path.join(HERE, "puct.npz")], scratch)
     if only in (None, "units"):
         run_child(["units", os.path.join(HERE, "units_S9.npz")], scratch)
+    if only in (None, "gtp"):
+        run_child(["gtp", os.path.join(HERE, "gtp_S9.npz")], scratch)
     if only in (None, "sync"):
         for i, c in enumerate(SYNC_CASES):
             run_child(["sync"] + list(c) + [os.path.join(HERE, "sync_%02d.npz" % i)], scratch)

@@ -228,3 +228,45 @@ def test_two_model_evaluation_game_matches_reference(sync_env, fn, monkeypatch):
     if int(z["winner"]) in (0, 1):
         true_winner = gd['modelB_name'] if int(z["winner"]) == 1 else gd['modelW_name']
         assert (gd['winner_model'] == true_winner) == model1_black
+
+
+def test_gtp_session_matches_reference(sync_env):
+    """The reference's GTP front-end (sejonggo_nomodel.py:20-160) replayed command for command: replies, the board after
+    every command and the kept subtree after every genmove (tests/golden/gtp_S9.npz, recorded from the reference with the
+    rounding-free stub net; temperature 0, no noise -> deterministic)."""
+    from sejonggo_amd import gtp, predicting_queue_worker as pq
+    from sejonggo_amd.stub_nets import make_stub
+    from tests.helpers import dict_tree_hash, name_of
+    z = load("gtp_S9.npz")
+    S = int(z["size"])
+    sync_env.update({'SIZE': S, 'MCTS_SIMULATIONS': int(z["sims"]), 'ENERGY': int(z["energy"]), 'KOMI': float(z["komi"]), 'GPUs': [0]})
+    net = make_stub("hash", S)
+    seen = [0]
+
+    class Counting(object):
+        name, numpy_native = net.name, True
+
+        def predict_on_batch(self, X):
+            seen[0] += len(X)
+            return net.predict_on_batch(X)
+
+    pq.set_model_factory(lambda kind: Counting())
+    try:
+        e = gtp.GTPEngine()
+        script = name_of(z, "script").split("\n")
+        replies = name_of(z, "replies").split("\x1e")
+        assert len(script) == len(replies) == len(z["board_hash"])
+        for i, cmd in enumerate(script):
+            assert e.parse_command(cmd) == replies[i], (i, cmd)
+            assert np.array_equal(sha8(e.sejong_engine.board), z["board_hash"][i]), (i, cmd)
+            assert e.sejong_engine.board[0, 0, 0, -1] == z["to_play"][i]
+            t = e.sejong_engine.mcts_tree
+            if cmd.startswith("genmove") and int(z["n_nodes"][i]) > 0:
+                h, nn = dict_tree_hash(t)
+                assert nn == int(z["n_nodes"][i]) and h == z["tree_hash"][i].tobytes(), (i, cmd)
+            elif int(z["n_nodes"][i]) == 0:
+                assert t is None or not t['subtree'], (i, cmd)
+        assert seen[0] == int(z["n_predict"])
+    finally:
+        pq.set_model_factory(None)
+        pq.destroy_predicting_workers([0])
