@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--symmetry", default="random1", choices=["random1", "avg8", "identity"])
     ap.add_argument("--net", default="resnet", choices=["resnet", "uniform", "hash"])
     ap.add_argument("--split-streams", type=int, default=0, help="evaluate the net as two half batches on two streams")
+    ap.add_argument("--tail-split", type=int, default=0, help="0: evaluate every batch as one launch chain (A/B of net.FusedInferenceNet._tail_split)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearse the N>1 path on fewer GPUs than ranks (ranks share devices, CPU tensors in the collectives)")
     ap.add_argument("--plain-net", type=int, default=0, help="1: plain PyTorch module instead of the fused inference net")
@@ -278,6 +279,7 @@ def run_rank(args):
         else:
             net, _ = build_fused_net(S, args.blocks, args.channels, name="bench_%db" % args.blocks, seed=0, device="cuda")
             net.split_streams = bool(args.split_streams)
+            net.tail_split = bool(args.tail_split)
     else:
         net = make_stub(args.net, S)
     # replicas take their weights from rank 0 (one RCCL broadcast), checked identical by checksum
@@ -319,6 +321,7 @@ def run_rank(args):
     time_convs = args.net == "resnet" and not args.plain_net and hasattr(net, "conv_events")
     if time_convs:
         net.conv_events = []
+        net.side_flops = 0.0
         # launches shorter than ~0.5 ms are sampled (1 in 16): two event calls per launch would make the host the bottleneck
         net.conv_event_stride = 1 if G * E * (S - 2) * (S - 2) >= (1 << 20) else 16
     evals0 = eng.status.total_evals
@@ -342,6 +345,10 @@ def run_rank(args):
             conv_ms += ms; conv_fl += f; conv_n += 1
             if f == big:
                 conv_big_ms += ms; conv_big_n += 1; conv_big_fl = f
+        # tail launches of split batches ran on the side stream INSIDE the bracketed launches' wall time: their FLOPs count,
+        # their time is already in conv_ms (net.FusedInferenceNet._tail_split)
+        conv_side_fl = net.side_flops * (1.0 / net.conv_event_stride)
+        conv_fl += conv_side_fl
     out = None
     if rank == 0:
         positions = world * G * args.steps
@@ -391,7 +398,10 @@ def run_rank(args):
                                "largest_batch": {"launches": conv_big_n, "avg_launch_ms": conv_big_ms / max(conv_big_n, 1),
                                                  "flops_per_launch": conv_big_fl,
                                                  "achieved": conv_big_fl * conv_big_n / max(conv_big_ms * 1e-3, 1e-12) / 1e12},
-                               "share_of_step_time": conv_ms * 1e-3 / dt}
+                               "share_of_step_time": conv_ms * 1e-3 / dt,
+                               "tail_split": {"enabled": bool(getattr(net, "tail_split", False)), "side_stream_flops": conv_side_fl,
+                                              "note": "8 192 positions = 9 248 tiles = 36.1 rounds of 256 workgroups; the 29 positions "
+                                                      "beyond 36 whole rounds run on a side stream inside the main launches' wall time"}}
             pc = os.path.join(ROOT, "profiles", "r02_pmc_conv.json")
             if os.path.isfile(pc) and (S, G, E) == (19, 1024, 8):
                 try:   # HBM bytes per 8192-batch launch: separate --pmc passes; FETCH_SIZE doubled (gfx950 wide-read correction)

@@ -170,10 +170,13 @@ class FusedInferenceNet(object):
         self.v_fc2_w, self.v_fc2_b = f.v_fc2.weight.to(dev, dtype).contiguous(), f.v_fc2.bias.to(dev, dtype).contiguous()
         self._flops = net.flops_per_eval()
         self.split_streams = False
+        self.tail_split = False    # see _tail_split(): measured -1.4 % end to end on MI355X (bench.py --tail-split 1), off
+        self.n_cu = None
         self.fused_conv = True     # conv + bias + skip + ReLU in one MFMA kernel (sgo_conv.hip); False: MIOpen + k_bias_act
         self.split_min = 1024
         self._side = None
         self.conv_events = None    # list of (start, end, flops) HIP-event brackets around tower convolutions while set (bench.py)
+        self.side_flops = 0.0      # tower FLOPs issued on the side stream while conv_events is set
         self.conv_event_stride = 1  # bracket every k-th tower launch only (small batches: the event calls would bound the host)
         self._conv_seq = 0
 
@@ -203,6 +206,11 @@ class FusedInferenceNet(object):
         y = torch.empty((n, k, h + 2 * pad - 2, wd + 2 * pad - 2), dtype=x.dtype, device=x.device,
                         memory_format=torch.channels_last)
         timed = self.conv_events is not None and c == k == 256 and pad == 1
+        if timed and self._side is not None and torch.cuda.current_stream() == self._side:
+            # the tail of a split batch runs CONCURRENTLY with the main part: its FLOPs are credited to the main stream's
+            # launch time (bench.py), a bracket of its own would count the same wall time twice
+            self.side_flops += 2.0 * n * y.shape[2] * y.shape[3] * 9 * c * k
+            timed = False
         if timed:
             self._conv_seq += 1
             timed = self._conv_seq % self.conv_event_stride == 0
@@ -216,6 +224,25 @@ class FusedInferenceNet(object):
             e1.record()
             self.conv_events.append((e0, e1, 2.0 * n * y.shape[2] * y.shape[3] * 9 * c * k))
         return y
+
+    def _tail_split(self, n):
+        """The tower kernel runs one 256-pixel tile per workgroup and one workgroup per CU (its LDS fills the CU), so a launch
+        takes ceil(tiles / CUs) rounds: 8 192 positions x 17 x 17 = 9 248 tiles = 36.1 rounds on 256 CUs cost 37, the last one
+        with 32 tiles on 224 idle CUs -- 2.4 % of every launch.  Returns how many leading positions fill whole rounds when the
+        rest is a small tail (it then runs on a side stream through all layers, its few workgroups slipping into the main
+        part's round boundaries), or 0 when splitting does not pay."""
+        if self.channels != 256 or self.t > 19:
+            return 0
+        if self.n_cu is None:
+            self.n_cu = torch.cuda.get_device_properties(self.device).multi_processor_count
+        t2 = self.t * self.t
+        tiles = -(-n * t2 // 256)
+        rounds = tiles // self.n_cu
+        rem = tiles - rounds * self.n_cu
+        if rounds < 8 or rem == 0 or rem > self.n_cu // 4:
+            return 0
+        h = (rounds * self.n_cu * 256) // t2          # positions whose tiles fit the whole rounds
+        return h if 0 < h < n else 0
 
     def _forward(self, X):
         n = X.shape[0]
@@ -238,7 +265,8 @@ class FusedInferenceNet(object):
     def predict_on_batch(self, X):
         """X: [n,S,S,32] fp16 CUDA (channel-padded NHWC) or [n,S,S,17] (padded here).
 
-        With `split_streams` the batch is evaluated as two halves on two HIP streams, so that one half's HBM-bound
+        With `tail_split` (off by default: measured slower) a batch whose tower tiles do not fill whole rounds of the chip is split unevenly (see
+        _tail_split).  With `split_streams` the batch is evaluated as two halves on two HIP streams, so that one half's HBM-bound
         epilogue passes can overlap the other half's MFMA-bound convolutions."""
         if not torch.is_tensor(X):
             import numpy as np
@@ -247,12 +275,14 @@ class FusedInferenceNet(object):
         if X.shape[-1] == 17:
             X = F.pad(X, (0, 15))
         n = X.shape[0]
-        if not self.split_streams or n < 2 * self.split_min or n % 2:
-            return self._forward(X)
+        h = self._tail_split(n) if self.tail_split and not self.split_streams else 0
+        if h == 0:
+            if not self.split_streams or n < 2 * self.split_min or n % 2:
+                return self._forward(X)
+            h = n // 2
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
         cur = torch.cuda.current_stream()
-        h = n // 2
         self._side.wait_stream(cur)
         with torch.cuda.stream(self._side):
             p1, v1 = self._forward(X[h:])
