@@ -38,9 +38,12 @@ def value_target(winner, player, move_n, compat=None):
 
 def _write_sample(directory, move_data, winner):
     vt = value_target(winner, move_data['player'], move_data['move_n'])
-    board = np.asarray(move_data['board'], dtype=np.float32)
-    pol = np.asarray(move_data['policy'], dtype=np.float32)
-    val = np.array(vt, dtype=np.float32)
+    _write_sample_arrays(directory, np.asarray(move_data['board'], dtype=np.float32), np.asarray(move_data['policy'], dtype=np.float32),
+                         np.array(vt, dtype=np.float32))
+
+
+def _write_sample_arrays(directory, board, pol, val):
+    """sample.h5 of one position: board f32 (1,S,S,17), policy_target f32 (S*S+1), value_target f32 ()."""
     lite = None if HAVE_H5 else _h5lite()
     if HAVE_H5 or lite is not None:
         if HAVE_H5:

@@ -395,3 +395,37 @@ def test_driver_smoke_entry():
     """__graft_entry__.smoke() -- what the driver runs before the bench -- stays runnable."""
     import __graft_entry__ as g
     g.smoke()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,backend", [(2, "gloo"), (1, "nccl")])
+def test_distributed_selfplay_gathers_tuples_to_rank0(tmp_path, world, backend):
+    """sejonggo_amd.dist_selfplay: N ranks (here 2 over gloo sharing the one GPU of the box, and 1 over RCCL), games sharded
+    g -> rank g mod N, weights broadcast from rank 0, finished games gathered to rank 0 as packed (s, pi, z) tuples and
+    written there in the reference's sample layout.  Every game number must come out exactly once and complete."""
+    import json
+    from tests.helpers import read_sample
+    over = dict(MODEL_DIR=str(tmp_path / "models"), SELF_PLAY_DIR=str(tmp_path / "selfplay"), EVAL_DIR=str(tmp_path / "eval"),
+                LOG_DIR=str(tmp_path / "logs"), TMP_DIR=str(tmp_path / "tmp"), GAMES_DIR=str(tmp_path / "eval"),
+                SIZE=9, N_RESIDUAL_BLOCKS=1, NET_CHANNELS=32, N_GAMES=7, GAMES_PER_GPU=3, MCTS_SIMULATIONS=16, ENERGY=8,
+                STOP_EXPLORATION=4, RESIGNATION_PERCENT=1.0, NUM_MOVES=12)
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", SGO_CONF_JSON=json.dumps(over), PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-m", "sejonggo_amd.dist_selfplay", "--gpus", str(world), "--backend", backend, "--sync-every", "3"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd="/tmp")
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
+    out = r.stdout
+    played = sorted(int(line.split(":")[1].split()[0]) for line in out.splitlines() if line.startswith("rank "))
+    assert sum(played) == 7 and len(played) == world
+    if world == 2:
+        assert played == [3, 4]                                  # games 1,3,5 on rank 1; 0,2,4,6 on rank 0
+    assert "%d positions written" % (7 * 12) in out
+    root = os.path.join(str(tmp_path), "selfplay", "model_1")
+    assert sorted(os.listdir(root)) == ["game_%05d" % g for g in range(7)]
+    for g in range(7):
+        moves = sorted(os.listdir(os.path.join(root, "game_%05d" % g)))
+        assert moves == ["move_%03d" % k for k in range(12)]
+        b, p, v = read_sample(os.path.join(root, "game_%05d" % g, "move_000", "sample.h5"))
+        assert b.shape == (1, 9, 9, 17) and b[0, :, :, :16].sum() == 0 and (b[0, :, :, 16] == 1).all()
+        assert p.shape == (82,) and v in (1.0, -1.0)
+        b5, _, _ = read_sample(os.path.join(root, "game_%05d" % g, "move_005", "sample.h5"))
+        assert (b5[0, :, :, 16] == -1).all() and 1 <= b5[0, :, :, :2].sum() <= 5      # white to play after five plies

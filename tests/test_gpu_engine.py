@@ -142,6 +142,42 @@ def _compare_with_oracle(eng, games, slots, S, sims, E, stop, nm, uni, noises, n
             assert t[k].tobytes() == np.asarray(o[k]).astype(t[k].dtype).tobytes(), (s, k)
 
 
+def test_full_length_19x19_games_equal_the_oracle(L):
+    """Six 19x19 games played to their END (2 * 361 plies, double pass or resignation): hundreds of re-roots with block
+    recycling, captures, ko shapes, passes, the temperature switch at move 30 and area scoring, against the oracle move for
+    move.  A thin search (16 sims) keeps the oracle's side to seconds; the rules / tree bookkeeping per ply is what is covered."""
+    from oracle import oracle as ora
+    from sejonggo_amd.engine import SelfPlayEngine
+    from sejonggo_amd.stub_nets import make_stub
+    S, sims, E, G = 19, 16, 8, 6
+    net = make_stub("hash", S)
+    rng = np.random.RandomState(99)
+    noises = rng.dirichlet([0.03] * (S * S + 1), size=G)
+    uni = rng.random_sample((G, 2 * S * S))
+    resign = [None, None, None, -0.85, None, -0.9]
+    eng = SelfPlayEngine(net, size=S, n_games=G, sims=sims, energy=E, stop_exploration=30, komi=5.5, symmetry="identity")
+    eng.start_games(np.arange(G), noises=noises, uniforms=uni, resign=resign)
+    games = {gd["slot"]: gd for gd in eng.run()}
+    res = eng.results()
+    assert len(games) == G
+    lengths = []
+    for s in range(G):
+        g = ora.Game(S, sims, E, 30, None, uniforms=uni[s], noises=noises[s:s + 1], resign=resign[s]).run(net)
+        r = g.result()
+        assert g.n_moves == len(games[s]["moves"]) == res[s]["n_moves"], s
+        assert r["end_reason"] == res[s]["end_reason"] and r["winner"] == res[s]["winner"], s
+        assert r["black"] == res[s]["black"] and r["white"] == res[s]["white"] and r["last_player"] == res[s]["last_player"], s
+        for i, mv in enumerate(games[s]["moves"]):
+            m = g.move(i)
+            assert mv["action"] == m["action"] and mv["player"] == m["player"], (s, i)
+            assert mv["value"].tobytes() == m["value"].tobytes() and mv["policy"].tobytes() == m["policy"].tobytes(), (s, i)
+            if i % 37 == 0 or i == g.n_moves - 1:
+                assert np.array_equal(mv["board"], m["board"]), (s, i)
+        lengths.append(g.n_moves)
+    assert max(lengths) > 150                      # real full-length games, not early stops
+    eng.close()
+
+
 def test_config5_search_width_equals_the_oracle(L):
     """BASELINE config 5's workload -- 19x19, 1 600 sims per move in rounds of 32 leaves (conf.py:18,29) -- with the
     default block pool (10 * sims + 64 = 16 064 blocks per game, k_search's > 64 KiB dynamic-LDS path): two concurrent
