@@ -59,3 +59,31 @@ def promote_best_model(cleanup=True):
                 clean_up_result(result)
             return True
     return False
+
+
+def elect_model_as_best_model(model):
+    """evaluator.py:17-20: N_GAMES of self-play with the new best model, then it replaces conf['BEST_MODEL']."""
+    from .model import save_model
+    from .self_play import self_play
+    self_play(model, n_games=conf['N_GAMES'], mcts_simulations=conf['MCTS_SIMULATIONS'])
+    save_model(getattr(model, "net", model), conf['BEST_MODEL'])
+
+
+def evaluate(best_model, tested_model):
+    """evaluator.py:22-47 (the sync path: self_play.play_game on host dict trees, rules and nets on the GPU): EVALUATE_N_GAMES
+    games best vs tested at temperature 0; above EVALUATE_MARGIN the tested model is elected.  Models are objects with the
+    numpy face of the model contract (predicting_queue_worker._NumpyNet wraps a resident net)."""
+    from .self_play import play_game
+    from .sgfsave import save_game_data
+    total = wins = 0
+    for game in range(conf['EVALUATE_N_GAMES']):
+        game_data = play_game(best_model, tested_model, conf['MCTS_SIMULATIONS'], stop_exploration=0)
+        if game_data['winner_model'] == tested_model.name:
+            wins += 1
+        total += 1
+        save_game_data(best_model.name, game, game_data)
+    if wins / total > conf['EVALUATE_MARGIN']:
+        print("We found a new best model : %s!" % tested_model.name)
+        elect_model_as_best_model(tested_model)
+        return True
+    return False

@@ -101,6 +101,11 @@ def _name_of_file(path):
     return keras_model_name(path) or os.path.basename(path).split('.')[0]
 
 
+def build_model(name):
+    """model.py:55-95: a new network of the reference's topology (random init) under `name`."""
+    return _build(name).eval()
+
+
 def save_model(net, fname):
     """fname: file name under MODEL_DIR (any extension is replaced by .pt).  Written atomically."""
     os.makedirs(_dir(), exist_ok=True)

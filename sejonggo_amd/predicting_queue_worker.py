@@ -164,3 +164,28 @@ class _NumpyNet(object):
             p = p.float().cpu().numpy()
             v = v.float().cpu().numpy()
         return p.astype(np.float32), v.astype(np.float32).reshape(-1, 1)
+
+
+class PredictingQueueWorker(object):
+    """predicting_queue_worker.py:23-106 is a Process that owns one GPU and serves the request queue.  Here nothing needs
+    serving -- leaf batching is on the device and single requests are answered in the caller's process -- so the class keeps
+    the constructor and the start / join / load_model surface for code that instantiates it, and does no work of its own."""
+
+    def __init__(self, gpu_id):
+        self.gpu_id = gpu_id
+        self.best_model = None
+        self.latest_model = None
+
+    def load_model(self):
+        init_predicting_workers([self.gpu_id])
+        self.best_model = get_model("BEST", self.gpu_id)
+        self.latest_model = get_model("LATEST", self.gpu_id)
+
+    def start(self):
+        init_predicting_workers([self.gpu_id])
+
+    def join(self, timeout=None):
+        return None
+
+    def run(self):
+        return None

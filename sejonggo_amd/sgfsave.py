@@ -151,3 +151,42 @@ def convert_npz_to_h5(root):
                     f.create_dataset(k, data=z[k], dtype=np.float32)
             n += 1
     return n
+
+
+def _short_games(model_self_play_dir, min_move):
+    for game_dir in sorted(os.listdir(model_self_play_dir)):
+        real_path = os.path.join(model_self_play_dir, game_dir)
+        try:
+            n = len(os.listdir(real_path))
+        except OSError:
+            continue
+        if n < min_move:
+            yield game_dir, real_path, n
+
+
+def clean_up(self_play_dir, min_move):
+    """sgfsave.py:83-96: remove every self-play game with fewer than `min_move` moves; returns how many."""
+    import shutil
+    total = 0
+    for model_dir in os.listdir(self_play_dir):
+        for _, real_path, _n in list(_short_games(os.path.join(self_play_dir, model_dir), min_move)):
+            shutil.rmtree(real_path)
+            total += 1
+    return total
+
+
+def statistic_by_model(model_self_play_dir, min_move):
+    """sgfsave.py:114-127: {number of moves: [game directories]} for the games shorter than min_move."""
+    stat = {i: [] for i in range(min_move)}
+    for game_dir, _, n in _short_games(model_self_play_dir, min_move):
+        stat[n].append(game_dir)
+    return stat
+
+
+def statistic_all_model(self_play_dir, min_move):
+    """sgfsave.py:99-112."""
+    stat = {i: [] for i in range(min_move)}
+    for model_dir in os.listdir(self_play_dir):
+        for game_dir, _, n in _short_games(os.path.join(self_play_dir, model_dir), min_move):
+            stat[n].append(game_dir)
+    return stat

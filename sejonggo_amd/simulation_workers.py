@@ -103,6 +103,12 @@ def init_simulation_workers_by_gpuid(GPU_ID):
     process_pool = _InlinePool()
 
 
+def init_pool_param(l):
+    """simulation_workers.py:31-33."""
+    global lock
+    lock = l
+
+
 def destroy_simulation_workers():
     """simulation_workers.py:36-39."""
     global process_pool

@@ -123,3 +123,47 @@ def random_symmetry_predict(model, board):
     symm_policy, value = model.predict_on_batch(symm_board)
     policy = reverse_symmetry(np.array(symm_policy, dtype=np.float32))
     return policy, value
+
+
+# The reference's module-level SWAP tables and their builders (symmetry.py:12-42, :44-114).  The tables come from the library
+# (sgo_sym_lut restates the float rotation + round construction); the builders restate the formula for callers that ask
+# for other angles.
+_SWAP_NAMES = {"LEFT_DIAGONAL_SWAP": 1, "VERTICAL_AXIS_SWAP": 2, "HORIZONTAL_AXIS_SWAP": 3, "ROTATION_90_SWAP": 4,
+               "ROTATION_180_SWAP": 5, "ROTATION_270_SWAP": 6, "RIGHT_DIAGONAL_SWAP": 7}
+
+
+def __getattr__(name):
+    if name in _SWAP_NAMES:
+        from .conf import conf
+        return [int(v) for v in sym_lut(conf['SIZE'], _SWAP_NAMES[name])]
+    raise AttributeError(name)
+
+
+def rotation_indexes(angle, size=None):
+    from math import cos, sin
+    from .conf import conf
+    S = size or conf['SIZE']
+    c = (S - 1) / 2
+    out = [0] * (S * S + 1)
+    for y in range(S):
+        for x in range(S):
+            nx = cos(angle) * (x - c) - sin(angle) * (y - c) + c
+            ny = sin(angle) * (x - c) + cos(angle) * (y - c) + c
+            out[x + S * y] = int(round(nx + S * ny))
+    out[S * S] = S * S
+    return out
+
+
+def axis_symmetry_indexes(angle, size=None):
+    from math import cos, sin
+    from .conf import conf
+    S = size or conf['SIZE']
+    c = (S - 1) / 2
+    out = [0] * (S * S + 1)
+    for y in range(S):
+        for x in range(S):
+            nx = cos(2 * angle) * (x - c) + sin(2 * angle) * (y - c) + c
+            ny = sin(2 * angle) * (x - c) - cos(2 * angle) * (y - c) + c
+            out[x + S * y] = int(round(nx + S * ny))
+    out[S * S] = S * S
+    return out

@@ -32,3 +32,10 @@ def clean_up_empty():
     except Exception as e:
         print("EXCEPTION WHILE CLEANING FOLDERS!!")
         print(e)
+
+
+def _colour(code):
+    return lambda prt: print("\033[%dm %s\033[00m" % (code, prt))
+
+
+prRed, prGreen, prYellow, prLightPurple, prPurple, prCyan, prLightGray, prBlack = (_colour(c) for c in range(91, 99))

@@ -206,3 +206,84 @@ def test_keras_layer_mapping_round_trip():
         assign_keras_layers(PolicyValueNet(9, n_blocks=5, channels=8), layers)
     with pytest.raises(ValueError):
         assign_keras_layers(PolicyValueNet(9, n_blocks=5, channels=16), [l for l in layers if l[0] != "policy_out"])
+
+
+def test_symmetry_index_builders_reproduce_the_library_tables():
+    """symmetry.py:12-42: rotation_indexes / axis_symmetry_indexes (float rotation + round) at the angles the reference uses
+    give exactly the SWAP tables of the library (which the goldens pin), and the module-level *_SWAP names resolve."""
+    import math
+    from sejonggo_amd import symmetry as sy
+    from sejonggo_amd.conf import conf
+    old = conf['SIZE']
+    try:
+        for S in (5, 9, 19):
+            conf['SIZE'] = S
+            want = {k: [int(v) for v in sy.sym_lut(S, k)] for k in range(8)}
+            assert sy.axis_symmetry_indexes(math.pi / 4) == want[1] == sy.LEFT_DIAGONAL_SWAP
+            assert sy.axis_symmetry_indexes(math.pi / 2) == want[2] == sy.VERTICAL_AXIS_SWAP
+            assert sy.axis_symmetry_indexes(0) == want[3] == sy.HORIZONTAL_AXIS_SWAP
+            assert sy.rotation_indexes(math.pi / 2) == want[4] == sy.ROTATION_90_SWAP
+            assert sy.rotation_indexes(math.pi) == want[5] == sy.ROTATION_180_SWAP
+            assert sy.rotation_indexes(3 * math.pi / 2) == want[6] == sy.ROTATION_270_SWAP
+            assert sy.axis_symmetry_indexes(-math.pi / 4) == want[7] == sy.RIGHT_DIAGONAL_SWAP
+    finally:
+        conf['SIZE'] = old
+
+
+def test_self_play_dir_statistics_and_clean_up(tmp_path):
+    """sgfsave.py:83-127."""
+    from sejonggo_amd import sgfsave
+    for model, games in (("m1", {0: 3, 1: 60, 2: 0}), ("m2", {5: 10})):
+        for g, n in games.items():
+            for k in range(n):
+                os.makedirs(os.path.join(str(tmp_path), model, "game_%05d" % g, "move_%03d" % k))
+            os.makedirs(os.path.join(str(tmp_path), model, "game_%05d" % g), exist_ok=True)
+    st = sgfsave.statistic_by_model(os.path.join(str(tmp_path), "m1"), 50)
+    assert st[3] == ["game_00000"] and st[0] == ["game_00002"] and sum(len(v) for v in st.values()) == 2
+    al = sgfsave.statistic_all_model(str(tmp_path), 50)
+    assert al[10] == ["game_00005"] and sum(len(v) for v in al.values()) == 3
+    assert sgfsave.clean_up(str(tmp_path), 50) == 3
+    assert os.listdir(os.path.join(str(tmp_path), "m1")) == ["game_00001"] and os.listdir(os.path.join(str(tmp_path), "m2")) == []
+
+
+def test_reference_names_are_all_present():
+    """Every public function / class of the reference modules on the path has a counterpart of the same name in the mirror
+    (training-side Keras helpers of model.py and the michi debug printers of utils.py excepted)."""
+    import importlib
+    want = {
+        "play": ["str_coord", "index2coord", "coord2index", "gtpcoord2index", "get_surrounding", "get_liberties", "get_real_board",
+                 "_show_board", "show_board", "show_board_old", "capture_group", "take_stones", "swap_player", "make_play",
+                 "_color_adjoint", "color_board", "get_winner", "_get_points", "game_init", "choose_first_player",
+                 "top_one_with_virtual_loss", "top_one_action", "top_n_actions", "tree_depth", "show_tree", "new_tree", "new_subtree",
+                 "legal_moves"],
+        "symmetry": ["_id", "rotation_indexes", "axis_symmetry_indexes", "left_diagonal", "reverse_left_diagonal", "right_diagonal",
+                     "reverse_right_diagonal", "vertical_axis", "reverse_vertical_axis", "horizontal_axis", "reverse_horizontal_axis",
+                     "rotation_90", "reverse_rotation_90", "rotation_180", "reverse_rotation_180", "rotation_270",
+                     "reverse_rotation_270", "random_symmetry_predict", "SYMMETRIES"],
+        "tree_util": ["find_best_leaf_virtual_loss", "get_node_by_moves"],
+        "nomodel_self_play": ["update_root", "error_handler", "back_propagation", "async_simulate2", "async_simulate", "select_play",
+                              "play_game_async"],
+        "self_play": ["simulate", "mcts_decision", "select_play", "play_game", "model_self_play", "self_play"],
+        "simulation_workers": ["init_simulation_workers", "init_simulation_workers_by_gpuid", "init_pool_param",
+                               "destroy_simulation_workers", "basic_tasks2", "basic_tasks", "board_worker", "subtree_worker",
+                               "simulation_result_queue", "process_pool"],
+        "predicting_queue_worker": ["init_predicting_workers", "destroy_predicting_workers", "PredictingQueueWorker",
+                                    "put_name_request", "put_predict_request"],
+        "selfplay_worker": ["SelfPlayWorker", "NoModelSelfPlayWorker"],
+        "evaluate_worker": ["NoModelEvaluateWorker"],
+        "main_selfplay": ["main"],
+        "sgfsave": ["save_file", "save_game_data", "save_self_play_data", "clean_up", "statistic_all_model", "statistic_by_model",
+                    "save_game_sgf"],
+        "go_game": ["GoGame", "IllegalMove", "WHITE", "BLACK", "EMPTY", "RESIGN", "PASS"],
+        "model": ["build_model", "create_initial_model", "load_latest_model", "load_best_model", "load_model_by_name"],
+        "evaluator": ["elect_model_as_best_model", "evaluate", "eval_statistic", "promote_best_model", "clean_up_result"],
+        "utils": ["init_directories", "clean_up_empty", "prRed", "prGreen", "prYellow", "prLightPurple", "prPurple", "prCyan",
+                  "prLightGray", "prBlack"],
+    }
+    for mod, names in want.items():
+        m = importlib.import_module("sejonggo_amd." + mod)
+        for n in names:
+            assert hasattr(m, n), "%s.%s" % (mod, n)
+    from sejonggo_amd import predicting_queue_worker as pq
+    w = pq.PredictingQueueWorker(3)
+    assert w.gpu_id == 3 and w.join() is None
