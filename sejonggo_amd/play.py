@@ -375,6 +375,8 @@ def _color_adjoint(i, j, color, board):
     grown = (filled == color) & (np.asarray(tmp) == 0)
     for a, b in zip(*np.nonzero(grown)):
         board[a][b] = color
+    if rb[i][j] == 0 and grown.any():
+        board[i][j] = color          # an empty starting point is painted when the walk steps back onto it from a neighbour
     return board
 
 
