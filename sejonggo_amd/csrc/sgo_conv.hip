@@ -9,15 +9,23 @@
 // No library GEMM / convolution code is linked into libsgo_hip.so.
 #include "sgo_common.hpp"
 #include "sgo_conv8w.hpp"
+#include "sgo_conv4w.hpp"
 #include "sgo_stem.hpp"
 
 namespace {
+int g_tower_kernel = 0;       // 0: k_conv8w (one 512-thread workgroup per CU), 1: k_conv4w (two 256-thread workgroups per CU)
 long g_tower_slice_cap = 0;   // > 0: samples per launch of the tower kernel are capped (tests of the slice loop)
 }
 
 extern "C" long sgo_conv_tower_slice_cap(long cap) {
     const long old = g_tower_slice_cap;
     if (cap >= 0) g_tower_slice_cap = cap;
+    return old;
+}
+
+extern "C" int sgo_conv_tower_kernel(int mode) {
+    const int old = g_tower_kernel;
+    if (mode == 0 || mode == 1) g_tower_kernel = mode;
     return old;
 }
 
@@ -50,8 +58,10 @@ extern "C" int sgo_conv3x3_tower_dev(int n, int h, int w, const void *d_x, const
     for (long n0 = 0; n0 < n; n0 += max_n) {
         const int nn = (int)((n - n0 < max_n) ? (n - n0) : max_n);
         const char *s0 = d_skip ? (const char *)d_skip + n0 * per : nullptr;
-        if (sgo_conv8w::launch(nn, h, w, (const char *)d_x + n0 * per, d_w, d_bias, s0, (char *)d_y + n0 * per,
-                               (hipStream_t)stream) != 0) {
+        const int rc = g_tower_kernel == 1
+                           ? sgo_conv4w::launch(nn, h, w, (const char *)d_x + n0 * per, d_w, d_bias, s0, (char *)d_y + n0 * per, (hipStream_t)stream)
+                           : sgo_conv8w::launch(nn, h, w, (const char *)d_x + n0 * per, d_w, d_bias, s0, (char *)d_y + n0 * per, (hipStream_t)stream);
+        if (rc != 0) {
             set_error("sgo_conv3x3_tower_dev: launch rejected");
             return SGO_ERR_ARG;
         }

@@ -716,7 +716,40 @@ def test_stem_conv_kernel(L):
     assert torch.equal(y.float(), ref)
 
 
-def test_tower_conv_tile_order_slices_and_bounds(L):
+@pytest.fixture(params=[0, 1], ids=["k_conv8w", "k_conv4w"])
+def tower_kernel(request, L):
+    """Both hand-written tower kernels (sgo_conv8w.hpp: one 512-thread workgroup per CU; sgo_conv4w.hpp: two 256-thread
+    workgroups per CU) go through the same parity tests."""
+    lib = L.load()
+    old = lib.sgo_conv_tower_kernel(request.param)
+    yield request.param
+    lib.sgo_conv_tower_kernel(old)
+
+
+def test_tower_kernels_agree_bit_for_bit(L):
+    import torch
+    lib = L.load()
+    st = torch.cuda.current_stream().cuda_stream
+    torch.manual_seed(11)
+    for (n, h, wd, with_skip) in [(3, 17, 17, True), (64, 7, 7, False), (7, 5, 19, True), (1500, 17, 17, True), (2, 19, 19, False)]:
+        x = torch.relu(torch.randn(n, h, wd, 256, device="cuda") * 0.5).half()
+        w = (torch.randn(256, 3, 3, 256, device="cuda") * 0.03).half()
+        b = torch.randn(256, device="cuda").half()
+        skip = torch.randn(n, h, wd, 256, device="cuda").half() if with_skip else None
+        outs = []
+        for kern in (0, 1):
+            old = lib.sgo_conv_tower_kernel(kern)
+            try:
+                y = torch.full((n, h, wd, 256), 7.0, device="cuda", dtype=torch.float16)
+                L.check(lib.sgo_conv3x3_tower_dev(n, h, wd, x.data_ptr(), w.data_ptr(), b.data_ptr(),
+                                                  None if skip is None else skip.data_ptr(), y.data_ptr(), st))
+                outs.append(y)
+            finally:
+                lib.sgo_conv_tower_kernel(old)
+        assert torch.equal(outs[0], outs[1]), (n, h, wd, with_skip)       # same MFMA order per output: identical bits
+
+
+def test_tower_conv_tile_order_slices_and_bounds(L, tower_kernel):
     """The tower kernel's launch plumbing: (1) both tile orders (identity, XCD-contiguous incl. grids that are not a
     multiple of 8) give identical bits; (2) the slice loop of sgo_conv3x3_tower_dev, normally reached only beyond 2^31 bytes
     per tensor, exercised through the sample cap hook on ragged slice sizes; (3) shapes whose pixel index arithmetic would
@@ -767,7 +800,7 @@ def test_tower_conv_tile_order_slices_and_bounds(L):
         assert bool((err <= 2e-3 * ref.abs() + 2e-3).all()), (i, float(err.max()))
 
 
-def test_tower_conv_kernel(L):
+def test_tower_conv_kernel(L, tower_kernel):
     """sgo_conv3x3_tower_dev, the hand-written CDNA4 kernel (csrc/sgo_conv8w.hpp): against torch conv2d in fp32 (tolerance:
     fp16 output rounding, 2e-3 relative + 2e-3 absolute), against the generic back end, bit-identical across repeated
     launches (the race screen for its hand-placed waits), on full / ragged / single-tile batches and both tower sizes."""

@@ -27,21 +27,25 @@ def main():
     def run():
         L.check(lib.sgo_conv3x3_tower_dev(n, h, w, L.ptr(x), L.ptr(wt), L.ptr(b), L.ptr(skip), L.ptr(y), st))
 
-    arms = [("identity tile order", 0), ("XCD-contiguous tile order", 1)]
+    def select(mode):
+        lib.sgo_conv_tile_order(mode & 1)
+        lib.sgo_conv_tower_kernel(mode >> 1)
+
+    arms = [("k_conv8w, identity tile order", 0), ("k_conv8w, XCD-contiguous tiles", 1), ("k_conv4w (2 workgroups / CU)", 3)]
     outs = {}
     for name, mode in arms:
-        lib.sgo_conv_tile_order(mode)
+        select(mode)
         run()
         torch.cuda.synchronize()
         outs[name] = y.clone()
-    assert torch.equal(outs[arms[0][0]], outs[arms[1][0]]), "tile order changed the result"
+    assert all(torch.equal(outs[arms[0][0]], o) for o in outs.values()), "an arm changed the result"
     for _ in range(10):
         run()
     ms = {name: 0.0 for name, _ in arms}
     evs = []
     for it in range(iters):
         for name, mode in arms:
-            lib.sgo_conv_tile_order(mode)
+            select(mode)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             run()
@@ -52,8 +56,8 @@ def main():
         ms[name] += e0.elapsed_time(e1)
     for name, _ in arms:
         t = ms[name] / iters
-        print("%-28s %.4f ms  %.0f TFLOP/s" % (name, t, fl / t / 1e9), flush=True)
-    lib.sgo_conv_tile_order(1)
+        print("%-34s %.4f ms  %.0f TFLOP/s" % (name, t, fl / t / 1e9), flush=True)
+    select(1)
 
 
 if __name__ == "__main__":
