@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--symmetry", default="random1", choices=["random1", "avg8", "identity"])
     ap.add_argument("--net", default="resnet", choices=["resnet", "uniform", "hash"])
     ap.add_argument("--split-streams", type=int, default=0, help="evaluate the net as two half batches on two streams")
+    ap.add_argument("--tower-kernel", type=int, default=-1, help="0: k_conv8w, 1: k_conv4w, -1: the library's default")
     ap.add_argument("--tail-split", type=int, default=0, help="0: evaluate every batch as one launch chain (A/B of net.FusedInferenceNet._tail_split)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearse the N>1 path on fewer GPUs than ranks (ranks share devices, CPU tensors in the collectives)")
@@ -273,6 +274,9 @@ def run_rank(args):
     from sejonggo_amd.stub_nets import make_stub
     from sejonggo_amd.distributed import tuple_dtype, gather_tuples
     S, G, sims, E = args.size, args.games, args.sims, args.energy
+    if args.tower_kernel >= 0:
+        from sejonggo_amd import _lib as _L
+        _L.load().sgo_conv_tower_kernel(args.tower_kernel)
     if args.net == "resnet":
         if args.plain_net:
             net = build_net(S, args.blocks, args.channels, name="bench_%db" % args.blocks, seed=0, device="cuda")

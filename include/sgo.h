@@ -127,9 +127,9 @@ int sgo_conv3x3_tower_dev(int n, int h, int w, const void *d_x, const void *d_w,
 /* The hand-written CDNA4 kernel for the stem (c = 32: the 17 input planes zero-padded, k = 256, pad 0, no skip;
  * csrc/sgo_stem.hpp; model.py:57-60).  x [n][h][w][32] is the network-input row format of sgo_step_fused / layout 2. */
 int sgo_conv3x3_stem_dev(int n, int h, int w, const void *d_x, const void *d_w, const void *d_bias, void *d_y, void *stream);
-/* Which hand-written kernel sgo_conv3x3_tower_dev launches: 0 = k_conv8w (csrc/sgo_conv8w.hpp: one 512-thread workgroup per
- * CU, 256 pixels x 256 channels), 1 = k_conv4w (csrc/sgo_conv4w.hpp: two 256-thread workgroups per CU, 256 pixels x 128
- * channels each).  Same results bit for bit.  Returns the previous choice; other values only query. */
+/* Which hand-written kernel sgo_conv3x3_tower_dev launches: 1 = k_conv4w (csrc/sgo_conv4w.hpp: two 256-thread workgroups per
+ * CU, 256 pixels x 128 channels each; the default), 0 = k_conv8w (csrc/sgo_conv8w.hpp: one 512-thread workgroup per CU,
+ * 256 pixels x 256 channels).  Same results bit for bit.  Returns the previous choice; other values only query. */
 int sgo_conv_tower_kernel(int mode);
 /* Tile order of the tower kernel's launches: 1 = every XCD walks a contiguous range of pixel tiles (default: the halo rows
  * a tile shares with its neighbour are then in that XCD's L2), 0 = identity.  Returns the previous mode; other values query. */

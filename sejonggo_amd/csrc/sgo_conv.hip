@@ -13,7 +13,7 @@
 #include "sgo_stem.hpp"
 
 namespace {
-int g_tower_kernel = 0;       // 0: k_conv8w (one 512-thread workgroup per CU), 1: k_conv4w (two 256-thread workgroups per CU)
+int g_tower_kernel = 1;       // 1: k_conv4w (two 256-thread workgroups per CU; default, +2-3 %), 0: k_conv8w (one 512-thread workgroup per CU)
 long g_tower_slice_cap = 0;   // > 0: samples per launch of the tower kernel are capped (tests of the slice loop)
 }
 

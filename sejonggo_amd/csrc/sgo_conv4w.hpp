@@ -30,6 +30,9 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef int intx2 __attribute__((ext_vector_type(2)));
 typedef int intx4 __attribute__((ext_vector_type(4)));
 
+#ifndef S4_MFMA_PRIO
+#define S4_MFMA_PRIO 1
+#endif
 #define S4_AS1 __attribute__((address_space(1)))
 #define S4_AS3 __attribute__((address_space(3)))
 
@@ -108,10 +111,11 @@ __global__ __launch_bounds__(256, 2) void k_conv4w(const char *__restrict__ xb, 
             S4_GLDS(src_, ((BUF) ? LB1 : LB0) + (G) * 8192 + (swid * 2 + i_) * 1024);                  \
         }                                                                                             \
     } while (0)
-// window piece id (8 rows) of the channel chunk at byte offset ccoff_ of a pixel row
-#define S4_STAGE_W(ccoff_)                                                                            \
+// window pieces (8 rows each) pc*4 + wid for pc in [PC0, PC1) of the channel chunk at byte offset ccoff_ of a pixel row
+#define S4_STAGE_W(ccoff_) S4_STAGE_WP(ccoff_, 0, 10)
+#define S4_STAGE_WP(ccoff_, PC0, PC1)                                                                 \
     do {                                                                                              \
-        _Pragma("nounroll") for (int pc_ = 0; pc_ < 10; pc_++) {                                      \
+        _Pragma("nounroll") for (int pc_ = (PC0); pc_ < (PC1); pc_++) {                               \
             const int id_ = pc_ * 4 + swid;                                                           \
             if (id_ * 8 < NROWS) {                                                                    \
                 int la_ = lane;                                                                       \
@@ -146,6 +150,7 @@ __global__ __launch_bounds__(256, 2) void k_conv4w(const char *__restrict__ xb, 
         dst[nt_][0] = S4_LDS16(((BUF) ? LB1 : LB0) + (G) * 8192 + nt_ * 2048 + rdB0);                 \
         dst[nt_][1] = S4_LDS16(((BUF) ? LB1 : LB0) + (G) * 8192 + nt_ * 2048 + rdB1);                 \
     }
+#define S4_PRIO(x) __builtin_amdgcn_s_setprio(x)
 #define S4_MFMA(QM, QN, wfrag)                                                                         \
     _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ks_++) _Pragma("unroll") for (int mt_ = 0; mt_ < 4; mt_++) \
         _Pragma("unroll") for (int nt_ = 0; nt_ < 2; nt_++) acc[QM][QN][mt_][nt_] =                    \
@@ -165,23 +170,31 @@ __global__ __launch_bounds__(256, 2) void k_conv4w(const char *__restrict__ xb, 
         S4_READ_A(0, T);                                                                                  \
         S4_LGKM0();                                                                                       \
         S4_BARRIER();                            /* every wave has read weights[t]: its buffer may be refilled */ \
+        /* last tap (shift +W+1): phase B reads window rows >= 128 + 2 (W + 1) only, so rows [0, 128) = pieces 0..15 are */ \
+        /* dead from here on (whatever W) and take the next chunk's window one phase early: 4 DMAs per wave */ \
+        if ((T) == 8 && cc < 3) S4_STAGE_WP((cc + 1) * 128, 0, 4);                                        \
+        S4_PRIO(S4_MFMA_PRIO);                                                                            \
         S4_MFMA(0, 0, wlo);                                                                               \
         S4_MFMA(0, 1, whi);                                                                               \
+        S4_PRIO(0);                                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                \
         S4_READ_A(1, T);                                                                                  \
         if (!last2_) {                                                                                    \
             const int koff_ = T2_ * (CIN * 2) + (cc + CARRY_) * 128;                                      \
             S4_STAGE_BK(BUF_, 0, koff_);                                                                  \
             S4_STAGE_BK(BUF_, 1, koff_);                                                                  \
-            S4_VMWAIT(4);                        /* weights[t+1] (issued one K-tile ago) have landed */     \
+            if ((T) == 8 && cc < 3) S4_VMWAIT(8);   /* ... with the 4 early window pieces of this tap also younger */ \
+            else S4_VMWAIT(4);                   /* weights[t+1] (issued one K-tile ago) have landed */     \
         } else if ((T) == 7) {                                                                            \
             S4_VMWAIT(0);                        /* K-tile 34: K-tile 35's weights */                       \
         }                                                                                                 \
         S4_LGKM0();                                                                                       \
         S4_BARRIER();                            /* weights[t+1] visible to all; window reads of this tap retired */ \
-        if ((T) == 8 && cc < 3) S4_STAGE_W((cc + 1) * 128);                                               \
+        if ((T) == 8 && cc < 3) S4_STAGE_WP((cc + 1) * 128, 4, 10);                                       \
+        S4_PRIO(S4_MFMA_PRIO);                                                                            \
         S4_MFMA(1, 1, whi);                                                                               \
         S4_MFMA(1, 0, wlo);                                                                               \
+        S4_PRIO(0);                                                                                       \
         __builtin_amdgcn_sched_barrier(0);       /* the next K-tile's fragment reads stay below these MFMAs (registers) */ \
         if ((T) == 8 && cc < 3) {                                                                         \
             S4_VMWAIT(0);                                                                                 \
@@ -360,6 +373,7 @@ static inline int launch(int n, int h, int w, const void *x, const void *wgt, co
 #undef S4_LDS16
 #undef S4_LGKM0
 #undef S4_MFMA
+#undef S4_PRIO
 #undef S4_READ_A
 #undef S4_READ_B
 #undef S4_SHIFT

@@ -174,3 +174,97 @@ def test_the_model_catches_the_round_1_race():
     nrows17 = 256 + 2 * 18
     assert (17, 7) in flagged and all(((4 * 8 + wid) * 8 >= 256 + 2 * (W + 1)) for W, wid in flagged)
     assert [(W, wid) for W, wid in flagged if W == 17] == [(17, wid) for wid in range(8) if (32 + wid) * 8 >= nrows17]
+
+
+# ------------------------------------------------------------------------------------------------ k_conv4w
+HDR4 = os.path.join(os.path.dirname(HDR), "sgo_conv4w.hpp")
+
+
+def test_conv4w_model_is_in_step_with_the_kernel_source():
+    s = open(HDR4).read()
+    assert "if ((T) == 8 && cc < 3) S4_STAGE_WP((cc + 1) * 128, 0, 4);" in s          # early pieces: rows [0, 128), 4 per wave
+    assert "if ((T) == 8 && cc < 3) S4_VMWAIT(8);" in s and "else S4_VMWAIT(4);" in s
+    assert "if ((T) == 8 && cc < 3) S4_STAGE_WP((cc + 1) * 128, 4, 10);" in s
+    assert re.search(r"if \(\(T\) == 8 && cc < 3\) \{\s*\\\s*S4_VMWAIT\(0\);", s)
+    assert "const int id_ = pc_ * 4 + swid;" in s and "if (id_ * 8 < NROWS)" in s
+    assert "S4_VMWAIT(0);                        /* K-tile 34: K-tile 35's weights */" in s
+    assert re.search(r"S4_STAGE_W\(0\);\s*S4_STAGE_BK\(0, 0, 0\);\s*S4_STAGE_BK\(0, 1, 0\);\s*S4_STAGE_BK\(1, 0, CIN \* 2\);\s*S4_STAGE_BK\(1, 1, CIN \* 2\);", s)
+    assert "S4_VMWAIT(4);\n    asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\");   // the zero area" in s
+    assert "#define S4_SHIFT(T) (((T) / 3 == 0 ? -W : (T) / 3 == 2 ? W : 0) + (T) % 3 - 1)" in s
+
+
+def run_wave4(wid, W, has_skip, early=4):
+    """k_conv4w: 4 waves, single-buffered window.  Besides the vmcnt accounting this checks the LDS LIFETIME claim behind the
+    early restage: the window rows overwritten before the last tap's phase B are rows that phase B no longer reads."""
+    nrows = 256 + 2 * (W + 1)
+    w = Wave()
+
+    def pieces(chunk, pc0, pc1):
+        out = []
+        for pc in range(pc0, pc1):
+            idn = pc * 4 + wid
+            if idn * 8 < nrows:
+                w.issue(("win", chunk, idn))
+                out.append(idn)
+        return out
+
+    pieces(0, 0, 10)
+    for t in (0, 1):
+        for g in (0, 1):
+            for i in (0, 1):
+                w.issue(("wgt", t, g, i))
+    w.wait(4, [("wgt", 0, g, i) for g in (0, 1) for i in (0, 1)] + [("win", 0, pc * 4 + wid) for pc in range(10) if (pc * 4 + wid) * 8 < nrows],
+           "prologue")
+    for cc in range(4):
+        for T in range(9):
+            t = 9 * cc + T
+            where = "K-tile %d (wave %d, w %d)" % (t, wid, W)
+            boundary = T == 8 and cc < 3
+            if boundary:
+                got = pieces(cc + 1, 0, early)
+                # rows restaged now must lie below everything phase B of this tap still reads: min row = 128 + HALO + shift(8)
+                lowest_read = 128 + (W + 1) + (W + 1)
+                assert all((idn + 1) * 8 <= lowest_read for idn in got), where
+                assert len(got) == early                     # every wave issues the same number: the counted wait relies on it
+            last2 = cc == 3 and T >= 7
+            if not last2:
+                for g in (0, 1):
+                    for i in (0, 1):
+                        w.issue(("wgt", t + 2, g, i))
+                w.wait(4 + (early if boundary else 0), [("wgt", t + 1, g, i) for g in (0, 1) for i in (0, 1)], where)
+            elif T == 7:
+                w.wait(0, [("wgt", 35, g, i) for g in (0, 1) for i in (0, 1)], where)
+            if boundary:
+                pieces(cc + 1, early, 10)
+                w.wait(0, [("win", cc + 1, pc * 4 + wid) for pc in range(10) if (pc * 4 + wid) * 8 < nrows], where + " boundary")
+    for q in range(4):
+        w.issue(("bias", q))
+    if has_skip:
+        for hf in (0, 1):
+            for j in range(8):
+                w.issue(("skip", hf, j))
+    for hf in (0, 1):
+        if has_skip:
+            w.wait(8, [("skip", hf, j) for j in range(8)] + [("bias", q) for q in range(4)], "epilogue half %d" % hf)
+        elif hf == 0:
+            w.wait(0, [("bias", q) for q in range(4)], "epilogue (no skip)")
+        for j in range(8):
+            w.issue(("store", hf, j))
+    return w
+
+
+def test_conv4w_counted_waits_and_window_lifetime():
+    for W in (1, 3, 5, 7, 9, 13, 17, 19):
+        for has_skip in (False, True):
+            for wid in range(4):
+                run_wave4(wid, W, has_skip)
+
+
+def test_conv4w_model_rejects_a_too_early_restage():
+    """Five early pieces per wave (rows [0, 160)) would be fine at w = 17 but overwrite rows that phase B still reads on
+    narrower boards: the lifetime assertion must catch it (this was the first draft of the optimisation)."""
+    import pytest
+    for wid in range(4):
+        run_wave4(wid, 17, True, early=5)
+    with pytest.raises(AssertionError):
+        run_wave4(3, 7, True, early=5)           # wave 3's fifth piece covers rows 152..159; phase B reads from row 144 on
