@@ -20,7 +20,7 @@ LIB = os.path.join(HERE, "libsgo_hip.so")
 MANIFEST = LIB + ".manifest.json"
 SOURCES = ["sgo_rules.hip", "sgo_engine.hip", "sgo_conv.hip"]
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall",
-          "-Wno-unused-function"]
+          "-Wno-unused-function"] + os.environ.get("SGO_EXTRA_CFLAGS", "").split()
 LDFLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC"]
 
 

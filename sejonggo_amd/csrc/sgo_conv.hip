@@ -25,7 +25,7 @@ extern "C" long sgo_conv_tower_slice_cap(long cap) {
 
 extern "C" int sgo_conv_tower_kernel(int mode) {
     const int old = g_tower_kernel;
-    if (mode == 0 || mode == 1) g_tower_kernel = mode;
+    if (mode == 0 || mode == 1 || (mode >= 16 && mode < 32)) g_tower_kernel = mode;   // 16 + v: k_conv4w schedule variant v (A/B builds)
     return old;
 }
 
@@ -58,8 +58,9 @@ extern "C" int sgo_conv3x3_tower_dev(int n, int h, int w, const void *d_x, const
     for (long n0 = 0; n0 < n; n0 += max_n) {
         const int nn = (int)((n - n0 < max_n) ? (n - n0) : max_n);
         const char *s0 = d_skip ? (const char *)d_skip + n0 * per : nullptr;
-        const int rc = g_tower_kernel == 1
-                           ? sgo_conv4w::launch(nn, h, w, (const char *)d_x + n0 * per, d_w, d_bias, s0, (char *)d_y + n0 * per, (hipStream_t)stream)
+        const int rc = g_tower_kernel >= 1
+                           ? sgo_conv4w::launch(nn, h, w, (const char *)d_x + n0 * per, d_w, d_bias, s0, (char *)d_y + n0 * per, (hipStream_t)stream,
+                                                g_tower_kernel >= 16 ? g_tower_kernel - 16 : 7)
                            : sgo_conv8w::launch(nn, h, w, (const char *)d_x + n0 * per, d_w, d_bias, s0, (char *)d_y + n0 * per, (hipStream_t)stream);
         if (rc != 0) {
             set_error("sgo_conv3x3_tower_dev: launch rejected");

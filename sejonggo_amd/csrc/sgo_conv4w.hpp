@@ -30,9 +30,7 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef int intx2 __attribute__((ext_vector_type(2)));
 typedef int intx4 __attribute__((ext_vector_type(4)));
 
-#ifndef S4_MFMA_PRIO
-#define S4_MFMA_PRIO 1
-#endif
+#define S4_MFMA_PRIO (VAR & 1)
 #define S4_AS1 __attribute__((address_space(1)))
 #define S4_AS3 __attribute__((address_space(3)))
 
@@ -53,7 +51,13 @@ constexpr int LW = 0, LB0 = 40960, LB1 = 57344, LZ = 73728, LZ_BYTES = 3 * 2048 
     __builtin_amdgcn_s_barrier();      \
     __builtin_amdgcn_sched_barrier(0)
 
-template <bool HAS_SKIP>
+// VAR: schedule variants kept selectable for A/B runs in one process (sgo_conv_tower_kernel(16 + VAR)); 7 = all on = default
+//   bit 0: s_setprio(1) around the MFMA bursts; bit 1: split wait at chunk boundaries (early pieces now, late pieces one phase
+//   later); bit 2: early restage of the dead window rows [0, 128) during the last tap's phase A.  Same-process A/B at
+//   8192 x 17 x 17 (TFLOP/s): 0 -> 1312, 4 -> 1305, 5 -> 1314, 6 -> 1324, 7 -> 1342 (k_conv8w: 1310).  Measured and
+//   dropped: refilling the weight buffer after barrier 2 so that barrier 1 disappears (-4 %: the weights get less time to
+//   land), prefetching bias + skip rows into dead LDS behind the last K-tile's MFMAs (-2 %).
+template <bool HAS_SKIP, int VAR>
 __global__ __launch_bounds__(256, 2) void k_conv4w(const char *__restrict__ xb, const char *__restrict__ wb,
                                                     const _Float16 *__restrict__ bias, const char *__restrict__ skipb,
                                                     char *__restrict__ yb, int M, int H, int W, unsigned magicHW, unsigned magicW,
@@ -164,43 +168,61 @@ __global__ __launch_bounds__(256, 2) void k_conv4w(const char *__restrict__ xb, 
         int swid = wid;                                                                                   \
         asm volatile("" : "+s"(swid));                                                                    \
         const bool last2_ = cc == 3 && (T) >= 7;    /* K-tiles 34, 35: nothing left to stage */           \
+        const bool boundary_ = (T) == 8 && cc < 3;  /* last tap of a chunk that has a successor */        \
         S4_READ_B(BUF_, 0, wlo);                                                                          \
         S4_READ_B(BUF_, 1, whi);                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                \
         S4_READ_A(0, T);                                                                                  \
         S4_LGKM0();                                                                                       \
-        S4_BARRIER();                            /* every wave has read weights[t]: its buffer may be refilled */ \
+        /* barrier 1: every wave has read weights[t] (its buffer may be refilled) and, in the last tap, the window rows */ \
+        /* [0, 128) for the last time */                                                                  \
+        S4_BARRIER();                                                                                     \
         /* last tap (shift +W+1): phase B reads window rows >= 128 + 2 (W + 1) only, so rows [0, 128) = pieces 0..15 are */ \
         /* dead from here on (whatever W) and take the next chunk's window one phase early: 4 DMAs per wave */ \
-        if ((T) == 8 && cc < 3) S4_STAGE_WP((cc + 1) * 128, 0, 4);                                        \
+        if ((VAR & 4) && boundary_) S4_STAGE_WP((cc + 1) * 128, 0, 4);                                    \
         S4_PRIO(S4_MFMA_PRIO);                                                                            \
         S4_MFMA(0, 0, wlo);                                                                               \
         S4_MFMA(0, 1, whi);                                                                               \
         S4_PRIO(0);                                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                \
+        if ((VAR & 6) == 6 && (T) == 0 && cc > 0) {   /* first tap of a restaged chunk: phase A read rows [0, 128) only (the */ \
+            S4_VMWAIT(0);                        /* early pieces); the late pieces, issued a whole phase ago, are needed from here */ \
+            S4_BARRIER();                                                                                 \
+        }                                                                                                 \
         S4_READ_A(1, T);                                                                                  \
         if (!last2_) {                                                                                    \
             const int koff_ = T2_ * (CIN * 2) + (cc + CARRY_) * 128;                                      \
             S4_STAGE_BK(BUF_, 0, koff_);                                                                  \
             S4_STAGE_BK(BUF_, 1, koff_);                                                                  \
-            if ((T) == 8 && cc < 3) S4_VMWAIT(8);   /* ... with the 4 early window pieces of this tap also younger */ \
+            if ((VAR & 4) && boundary_) S4_VMWAIT(8);   /* ... with the 4 early window pieces also younger */ \
             else S4_VMWAIT(4);                   /* weights[t+1] (issued one K-tile ago) have landed */     \
         } else if ((T) == 7) {                                                                            \
             S4_VMWAIT(0);                        /* K-tile 34: K-tile 35's weights */                       \
         }                                                                                                 \
         S4_LGKM0();                                                                                       \
-        S4_BARRIER();                            /* weights[t+1] visible to all; window reads of this tap retired */ \
-        if ((T) == 8 && cc < 3) S4_STAGE_WP((cc + 1) * 128, 4, 10);                                       \
+        S4_BARRIER();                            /* barrier 2: weights[t+1] visible to all; this tap's window reads retired */ \
+        if (boundary_) S4_STAGE_WP((cc + 1) * 128, (VAR & 4) ? 4 : 0, 10);                                \
         S4_PRIO(S4_MFMA_PRIO);                                                                            \
         S4_MFMA(1, 1, whi);                                                                               \
         S4_MFMA(1, 0, wlo);                                                                               \
         S4_PRIO(0);                                                                                       \
         __builtin_amdgcn_sched_barrier(0);       /* the next K-tile's fragment reads stay below these MFMAs (registers) */ \
-        if ((T) == 8 && cc < 3) {                                                                         \
-            S4_VMWAIT(0);                                                                                 \
-            S4_BARRIER();                        /* the next chunk's window is in place */                 \
+        if (boundary_) {                                                                                  \
+            /* the next tap's phase A reads window rows [0, 128) = the EARLY pieces: the oldest of this wave's outstanding */ \
+            /* DMAs ([early x 4][weights x 4][late x nlate]); the late pieces get one more phase to land */ \
+            if ((VAR & 6) != 6) S4_VMWAIT(0);                                                             \
+            else if (nlate == 6) S4_VMWAIT(10);                                                           \
+            else if (nlate == 5) S4_VMWAIT(9);                                                            \
+            else if (nlate == 4) S4_VMWAIT(8);                                                            \
+            else S4_VMWAIT(0);                                                                            \
+            S4_BARRIER();                        /* rows [0, 128) of the next chunk's window are in place */ \
         }                                                                                                 \
     } while (0)
+
+    // late window pieces (pc 4..9) this wave issues at a chunk boundary: the counted wait there depends on it
+    int nlate = 0;
+#pragma unroll
+    for (int pc = 4; pc < 10; pc++) nlate += ((pc * 4 + wid) * 8 < NROWS) ? 1 : 0;
 
     // ---- prologue: window of chunk 0, weights of K-tiles 0 and 1
     {
@@ -344,8 +366,9 @@ __global__ __launch_bounds__(256, 2) void k_conv4w(const char *__restrict__ xb, 
     }
 }
 
-static inline int launch(int n, int h, int w, const void *x, const void *wgt, const void *bias, const void *skip, void *y,
-                         hipStream_t st) {
+template <int VAR>
+static inline int launch_var(int n, int h, int w, const void *x, const void *wgt, const void *bias, const void *skip, void *y,
+                             hipStream_t st) {
     const long M = (long)n * h * w;
     if (M <= 0 || M * ROWB >= (1L << 31) || w > MAXW || w < 1 || h < 1) return -1;
     if ((unsigned long long)(M + 256) * (unsigned long long)(h * w) >= (1ULL << 32)) return -1;
@@ -355,10 +378,23 @@ static inline int launch(int n, int h, int w, const void *x, const void *wgt, co
     const int per_xcd = 2 * (q + (r ? 1 : 0));        // (tile, half) pairs of the fullest XCD
     const dim3 grid(8 * per_xcd);
 #define S4_ARGS (const char *)x, (const char *)wgt, (const _Float16 *)bias, (const char *)skip, (char *)y, (int)M, h, w, mhw, mw, q, r
-    if (skip) hipLaunchKernelGGL(k_conv4w<true>, grid, dim3(256), 0, st, S4_ARGS);
-    else hipLaunchKernelGGL(k_conv4w<false>, grid, dim3(256), 0, st, S4_ARGS);
+    if (skip) hipLaunchKernelGGL((k_conv4w<true, VAR>), grid, dim3(256), 0, st, S4_ARGS);
+    else hipLaunchKernelGGL((k_conv4w<false, VAR>), grid, dim3(256), 0, st, S4_ARGS);
 #undef S4_ARGS
     return 0;
+}
+
+static inline int launch(int n, int h, int w, const void *x, const void *wgt, const void *bias, const void *skip, void *y,
+                         hipStream_t st, int var = 7) {
+    switch (var) {
+#ifdef SGO_CONV4W_VARIANTS
+    case 0: return launch_var<0>(n, h, w, x, wgt, bias, skip, y, st);
+    case 4: return launch_var<4>(n, h, w, x, wgt, bias, skip, y, st);
+    case 5: return launch_var<5>(n, h, w, x, wgt, bias, skip, y, st);
+    case 6: return launch_var<6>(n, h, w, x, wgt, bias, skip, y, st);
+#endif
+    default: return launch_var<7>(n, h, w, x, wgt, bias, skip, y, st);
+    }
 }
 
 }  // namespace sgo_conv4w
@@ -374,6 +410,7 @@ static inline int launch(int n, int h, int w, const void *x, const void *wgt, co
 #undef S4_LGKM0
 #undef S4_MFMA
 #undef S4_PRIO
+#undef S4_MFMA_PRIO
 #undef S4_READ_A
 #undef S4_READ_B
 #undef S4_SHIFT

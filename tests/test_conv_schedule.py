@@ -182,15 +182,20 @@ HDR4 = os.path.join(os.path.dirname(HDR), "sgo_conv4w.hpp")
 
 def test_conv4w_model_is_in_step_with_the_kernel_source():
     s = open(HDR4).read()
-    assert "if ((T) == 8 && cc < 3) S4_STAGE_WP((cc + 1) * 128, 0, 4);" in s          # early pieces: rows [0, 128), 4 per wave
-    assert "if ((T) == 8 && cc < 3) S4_VMWAIT(8);" in s and "else S4_VMWAIT(4);" in s
-    assert "if ((T) == 8 && cc < 3) S4_STAGE_WP((cc + 1) * 128, 4, 10);" in s
-    assert re.search(r"if \(\(T\) == 8 && cc < 3\) \{\s*\\\s*S4_VMWAIT\(0\);", s)
+    assert "const bool boundary_ = (T) == 8 && cc < 3;" in s
+    assert "if ((VAR & 4) && boundary_) S4_STAGE_WP((cc + 1) * 128, 0, 4);" in s          # early pieces: rows [0, 128), 4 per wave
+    assert "if ((VAR & 4) && boundary_) S4_VMWAIT(8);" in s and "else S4_VMWAIT(4);" in s
+    assert "if (boundary_) S4_STAGE_WP((cc + 1) * 128, (VAR & 4) ? 4 : 0, 10);" in s
+    assert "if ((VAR & 6) != 6) S4_VMWAIT(0);" in s
+    assert "else if (nlate == 6) S4_VMWAIT(10);" in s and "else if (nlate == 5) S4_VMWAIT(9);" in s and "else if (nlate == 4) S4_VMWAIT(8);" in s
+    assert re.search(r"if \(\(VAR & 6\) == 6 && \(T\) == 0 && cc > 0\) \{[^}]*S4_VMWAIT\(0\);[^}]*S4_BARRIER\(\);", s)
+    assert "for (int pc = 4; pc < 10; pc++) nlate += ((pc * 4 + wid) * 8 < NROWS) ? 1 : 0;" in s
     assert "const int id_ = pc_ * 4 + swid;" in s and "if (id_ * 8 < NROWS)" in s
     assert "S4_VMWAIT(0);                        /* K-tile 34: K-tile 35's weights */" in s
     assert re.search(r"S4_STAGE_W\(0\);\s*S4_STAGE_BK\(0, 0, 0\);\s*S4_STAGE_BK\(0, 1, 0\);\s*S4_STAGE_BK\(1, 0, CIN \* 2\);\s*S4_STAGE_BK\(1, 1, CIN \* 2\);", s)
     assert "S4_VMWAIT(4);\n    asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\");   // the zero area" in s
     assert "#define S4_SHIFT(T) (((T) / 3 == 0 ? -W : (T) / 3 == 2 ? W : 0) + (T) % 3 - 1)" in s
+    assert "default: return launch_var<7>(n, h, w, x, wgt, bias, skip, y, st);" in s          # the modelled variant is the shipped one
 
 
 def run_wave4(wid, W, has_skip, early=4):
@@ -220,6 +225,11 @@ def run_wave4(wid, W, has_skip, early=4):
             t = 9 * cc + T
             where = "K-tile %d (wave %d, w %d)" % (t, wid, W)
             boundary = T == 8 and cc < 3
+            if T == 0 and cc > 0:
+                # phase A read rows [0, 128) (checked below); before phase B everything of the new window must be there
+                lo_rows_max = (W + 1) + (-W - 1) + 63 + 48 + 15
+                assert lo_rows_max < 128
+                w.wait(0, [("win", cc, pc * 4 + wid) for pc in range(10) if (pc * 4 + wid) * 8 < nrows], where + " late pieces")
             if boundary:
                 got = pieces(cc + 1, 0, early)
                 # rows restaged now must lie below everything phase B of this tap still reads: min row = 128 + HALO + shift(8)
@@ -235,8 +245,10 @@ def run_wave4(wid, W, has_skip, early=4):
             elif T == 7:
                 w.wait(0, [("wgt", 35, g, i) for g in (0, 1) for i in (0, 1)], where)
             if boundary:
-                pieces(cc + 1, early, 10)
-                w.wait(0, [("win", cc + 1, pc * 4 + wid) for pc in range(10) if (pc * 4 + wid) * 8 < nrows], where + " boundary")
+                late = pieces(cc + 1, early, 10)
+                n = {6: 10, 5: 9, 4: 8}.get(len(late), 0) if early == 4 else 0
+                # the next tap's phase A reads rows [0, 128): pieces 0..15, i.e. this wave's early ones
+                w.wait(n, [("win", cc + 1, pc * 4 + wid) for pc in range(4)], where + " boundary (early pieces)")
     for q in range(4):
         w.issue(("bias", q))
     if has_skip:

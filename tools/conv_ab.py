@@ -28,10 +28,15 @@ def main():
         L.check(lib.sgo_conv3x3_tower_dev(n, h, w, L.ptr(x), L.ptr(wt), L.ptr(b), L.ptr(skip), L.ptr(y), st))
 
     def select(mode):
-        lib.sgo_conv_tile_order(mode & 1)
-        lib.sgo_conv_tower_kernel(mode >> 1)
+        if mode < 2:
+            lib.sgo_conv_tile_order(mode & 1)
+            lib.sgo_conv_tower_kernel(0)
+        else:
+            lib.sgo_conv_tower_kernel(mode)
 
-    arms = [("k_conv8w, identity tile order", 0), ("k_conv8w, XCD-contiguous tiles", 1), ("k_conv4w (2 workgroups / CU)", 3)]
+    arms = [("k_conv8w, identity tile order", 0), ("k_conv8w, XCD-contiguous tiles", 1), ("k_conv4w (2 workgroups / CU)", 16 + 7)]
+    if os.environ.get("SGO_AB_VARIANTS"):          # library built with -DSGO_CONV4W_VARIANTS
+        arms += [("k_conv4w var %d" % v, 16 + v) for v in (0, 4, 5, 6)]
     outs = {}
     for name, mode in arms:
         select(mode)
@@ -57,7 +62,8 @@ def main():
     for name, _ in arms:
         t = ms[name] / iters
         print("%-34s %.4f ms  %.0f TFLOP/s" % (name, t, fl / t / 1e9), flush=True)
-    select(1)
+    lib.sgo_conv_tile_order(1)
+    lib.sgo_conv_tower_kernel(1)
 
 
 if __name__ == "__main__":
