@@ -5,7 +5,7 @@ Contract (one JSON line on rank 0): see the task statement.  A "step" = every re
 by ONE move: 1 root evaluation + sims/energy search rounds of `energy` leaves each, i.e. (1 + 400)
 network evaluations, 400 board_advance leaf positions and one move record per game.
   value     = n_gpus * games_per_gpu * steps / seconds   (whole job, positions/sec)
-  roofline  = the step's dominant kernel (98 % of the GPU time): the hand-written tower convolution k_conv8w,
+  roofline  = the step's dominant kernel (98 % of the GPU time): the hand-written tower convolution (k_conv4w; k_conv8w with --tower-kernel 0),
               bound "mfma": FLOPs of its launches / their durations, every launch of the timed region bracketed by
               HIP events on the launch stream (both batch sizes; "largest_batch" = the games x energy batches alone)
   roofline_board_advance = the board_advance kernel in situ, bound "hbm": algorithmic bytes per launch (1834 B per
@@ -262,6 +262,11 @@ def main():
 
 
 def run_rank(args):
+    # stdout carries the result line and nothing else: libraries that print there from C (RCCL's version banner at communicator
+    # start) are sent to stderr by pointing fd 1 at fd 2 for the life of the rank; the line goes to the saved descriptor.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -396,7 +401,11 @@ def run_rank(args):
             # the dominant kernel of the step (98 % of the GPU time): the tower convolution, timed launch by launch with HIP
             # events on the launch stream inside the timed region; `achieved` is over ALL its launches (both batch sizes)
             ach = conv_fl / (conv_ms * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": "sgo_conv8w::k_conv8w (tower 3x3 convolution 256->256 + bias (+ skip) + ReLU, fp16 in / fp32 accumulate; csrc/sgo_conv8w.hpp)",
+            from sejonggo_amd import _lib as _L2
+            tk = _L2.load().sgo_conv_tower_kernel(-1)      # -1 leaves the selection as it is and returns it
+            kname = ("sgo_conv8w::k_conv8w (one 512-thread workgroup per CU; csrc/sgo_conv8w.hpp)" if tk == 0 else
+                     "sgo_conv4w::k_conv4w (two 256-thread workgroups per CU; csrc/sgo_conv4w.hpp)")
+            out["roofline"] = {"bound": "mfma", "kernel": kname + ": tower 3x3 convolution 256->256 + bias (+ skip) + ReLU, fp16 in / fp32 accumulate",
                                "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": None,
                                "launches": conv_n, "launches_sampled_1_in": net.conv_event_stride, "avg_launch_ms": conv_ms / conv_n, "flops_per_launch_mean": conv_fl / conv_n,
                                "largest_batch": {"launches": conv_big_n, "avg_launch_ms": conv_big_ms / max(conv_big_n, 1),
@@ -440,7 +449,8 @@ def run_rank(args):
                 out["cpu_baseline"] = cpu_baseline(args, S, sims, E, args.blocks, args.channels, args.symmetry)
             except Exception as ex:  # the GPU number stands on its own; say why the comparator is missing
                 out["cpu_baseline"] = {"value": None, "error": repr(ex)}
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     eng.close()
     dist.barrier()
     dist.destroy_process_group()

@@ -56,7 +56,10 @@ constexpr int LW = 0, LB0 = 40960, LB1 = 57344, LZ = 73728, LZ_BYTES = 3 * 2048 
 //   later); bit 2: early restage of the dead window rows [0, 128) during the last tap's phase A.  Same-process A/B at
 //   8192 x 17 x 17 (TFLOP/s): 0 -> 1312, 4 -> 1305, 5 -> 1314, 6 -> 1324, 7 -> 1342 (k_conv8w: 1310).  Measured and
 //   dropped: refilling the weight buffer after barrier 2 so that barrier 1 disappears (-4 %: the weights get less time to
-//   land), prefetching bias + skip rows into dead LDS behind the last K-tile's MFMAs (-2 %).
+//   land), prefetching bias + skip rows into dead LDS behind the last K-tile's MFMAs (-2 %), staging weights[t+2] right after
+//   barrier 1 instead of behind phase A's MFMAs (-7 %: whatever sits between a barrier and the MFMA burst is exposed, what
+//   follows the burst runs in its shadow), a fifth early window piece for W >= 15 (-1.3 %), s_setprio 3 (-1.9 %), window
+//   staging unrolled with v_med3 clamps, 8 instead of ~20 instructions per piece (+-0: instruction issue is not the limit).
 template <bool HAS_SKIP, int VAR>
 __global__ __launch_bounds__(256, 2) void k_conv4w(const char *__restrict__ xb, const char *__restrict__ wb,
                                                     const _Float16 *__restrict__ bias, const char *__restrict__ skipb,
@@ -194,8 +197,9 @@ __global__ __launch_bounds__(256, 2) void k_conv4w(const char *__restrict__ xb, 
             const int koff_ = T2_ * (CIN * 2) + (cc + CARRY_) * 128;                                      \
             S4_STAGE_BK(BUF_, 0, koff_);                                                                  \
             S4_STAGE_BK(BUF_, 1, koff_);                                                                  \
-            if ((VAR & 4) && boundary_) S4_VMWAIT(8);   /* ... with the 4 early window pieces also younger */ \
-            else S4_VMWAIT(4);                   /* weights[t+1] (issued one K-tile ago) have landed */     \
+            /* weights[t+1] (issued one K-tile ago) have landed; younger: weights[t+2] and this tap's early window pieces */ \
+            if ((VAR & 4) && boundary_) S4_VMWAIT(8);                                                     \
+            else S4_VMWAIT(4);                                                                            \
         } else if ((T) == 7) {                                                                            \
             S4_VMWAIT(0);                        /* K-tile 34: K-tile 35's weights */                       \
         }                                                                                                 \

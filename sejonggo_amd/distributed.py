@@ -45,12 +45,26 @@ def launch_ranks(argv, n_ranks, env=None, timeout=None, master_port=None):
     a fresh interpreter.  The caller's stdout / stderr are inherited (rank 0 prints the result line).  Returns 0, or
     the exit code of the first rank that failed (the others are then terminated), or 124 on timeout."""
     port = master_port or free_port()
+    # The ranks meet through a file (SGO_RDZV_FILE), not through MASTER_PORT: a port picked now can be taken by somebody else
+    # during the minute a fresh interpreter spends importing torch.  The port is still exported for code that wants one.
+    import tempfile
+    import time
+    rdzv_dir = tempfile.mkdtemp(prefix="sgo_rdzv_")
     procs = []
     for r in range(n_ranks):
         e = dict(os.environ if env is None else env)
-        e.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        e.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                 SGO_RDZV_FILE=os.path.join(rdzv_dir, "store"))
         e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable] + list(argv), env=e))
+    try:
+        return _wait_ranks(procs, n_ranks, timeout)
+    finally:
+        import shutil
+        shutil.rmtree(rdzv_dir, ignore_errors=True)
+
+
+def _wait_ranks(procs, n_ranks, timeout):
     import time
     t0 = time.time()
     codes = [None] * n_ranks
@@ -86,19 +100,27 @@ def init_from_env(backend="nccl"):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", str(free_port() if world == 1 else 29500))
+    # Rendezvous without a race on a TCP port where we control it: one rank needs no network at all (in-process HashStore),
+    # ranks started by launch_ranks meet through a file; only an external launcher's MASTER_ADDR / MASTER_PORT go over TCP.
+    kw = {}
+    if world == 1:
+        kw["store"] = dist.HashStore()
+    elif os.environ.get("SGO_RDZV_FILE"):
+        kw["store"] = dist.FileStore(os.environ["SGO_RDZV_FILE"], world)
+    else:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
     ndev = torch.cuda.device_count()
     if backend == "nccl":
         if local >= ndev:
             raise RuntimeError("rank %d needs device %d but only %d HIP device(s) are visible" % (rank, local, ndev))
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local), **kw)
         return rank, world, local
     dev = (local % ndev) if ndev > 0 else None
     if dev is not None:
         torch.cuda.set_device(dev)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, **kw)
     return rank, world, dev
 
 

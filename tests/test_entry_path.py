@@ -429,3 +429,23 @@ def test_distributed_selfplay_gathers_tuples_to_rank0(tmp_path, world, backend):
         assert p.shape == (82,) and v in (1.0, -1.0)
         b5, _, _ = read_sample(os.path.join(root, "game_%05d" % g, "move_005", "sample.h5"))
         assert (b5[0, :, :, 16] == -1).all() and 1 <= b5[0, :, :, :2].sum() <= 5      # white to play after five plies
+
+
+@pytest.mark.gpu
+def test_bench_stdout_is_one_json_line():
+    """The driver reads ONE JSON line from bench.py's stdout: whatever libraries print from C (RCCL's banner) must not land
+    there.  Small configuration (9x9, the real 256-channel tower so the roofline object names the tower kernel)."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--size", "9", "--games", "64", "--sims", "16", "--blocks", "2",
+                        "--steps", "1", "--warmup", "1", "--cpu-baseline", "0", "--saturated", "0", "--steady-state", "0"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = r.stdout.decode().splitlines()
+    assert len(lines) == 1, lines[:5]
+    out = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in out, k
+    assert out["n_gpus"] == 1 and out["steps"] == 1 and out["value"] > 0
+    assert "k_conv4w" in out["roofline"]["kernel"] and 0 < out["roofline"]["frac"] < 1

@@ -6,12 +6,12 @@ TAG=${1:-r02}
 cd /tmp; export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmcc_$c
-  timeout -k 10 400 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "k_conv8w" --output-format csv -d /tmp/pmcc_$c -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-baseline 0 --saturated 0 --steady-state 0 > /tmp/pmcc_$c.log 2>&1
+  timeout -k 10 400 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "k_conv[48]w" --output-format csv -d /tmp/pmcc_$c -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-baseline 0 --saturated 0 --steady-state 0 > /tmp/pmcc_$c.log 2>&1
   echo "pass $c exit=$?"
 done
 python3 - <<PY
 import csv, glob, json
-out = {"command": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --kernel-trace --kernel-include-regex k_conv8w -- python3 bench.py --steps 1 --warmup 0 --cpu-baseline 0 --saturated 0 --steady-state 0",
+out = {"command": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --kernel-trace --kernel-include-regex k_conv[48]w -- python3 bench.py --steps 1 --warmup 0 --cpu-baseline 0 --saturated 0 --steady-state 0",
        "note": "KiB per launch; the 8192-position launches are the upper half of the sorted values; gfx950 FETCH_SIZE under-counts 16 B/lane reads by 2x (guide): traffic = 2 x FETCH + WRITE; algorithmic x + skip + y + weights = 3.63 GB (no skip: 2.42 GB)"}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     v = []

@@ -1,11 +1,11 @@
 #!/bin/bash
-# MFMA utilisation of the net's dominant kernel (the hand-written tower convolution k_conv8w) inside the headline bench:
+# MFMA utilisation of the net's dominant kernel (the hand-written tower convolution k_conv4w (or k_conv8w when selected)) inside the headline bench:
 # one --pmc pass with --kernel-trace only.  Writes gpurun_out/<tag>_pmc_net.json
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=${1:-r01}
 cd /tmp; export TMPDIR=/tmp
 rm -rf /tmp/pmc_net
-timeout -k 10 500 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_MFMA GRBM_GUI_ACTIVE --kernel-trace --kernel-include-regex "k_conv8w" --output-format csv -d /tmp/pmc_net -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-baseline 0 --saturated 0 --steady-state 0 > /tmp/pmc_net.log 2>&1
+timeout -k 10 500 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_MFMA GRBM_GUI_ACTIVE --kernel-trace --kernel-include-regex "k_conv[48]w" --output-format csv -d /tmp/pmc_net -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-baseline 0 --saturated 0 --steady-state 0 > /tmp/pmc_net.log 2>&1
 echo "exit=$?"
 python3 - <<PY
 import csv, glob, json, collections
@@ -17,8 +17,8 @@ for f in glob.glob("/tmp/pmc_net/*/*counter_collection.csv"):
 for f in glob.glob("/tmp/pmc_net/*/*kernel_trace.csv"):
     for r in csv.DictReader(open(f)):
         dur.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-out = {"command": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_MFMA GRBM_GUI_ACTIVE --kernel-trace --kernel-include-regex k_conv8w -- python3 bench.py --steps 1 --warmup 0 --cpu-baseline 0 --saturated 0",
-       "kernel": "sgo_conv8w::k_conv8w<true/false> of csrc/sgo_conv8w.hpp (launches with the bigger batch dominate the upper half)"}
+out = {"command": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_MFMA GRBM_GUI_ACTIVE --kernel-trace --kernel-include-regex k_conv[48]w -- python3 bench.py --steps 1 --warmup 0 --cpu-baseline 0 --saturated 0",
+       "kernel": "sgo_conv4w::k_conv4w<true/false, 7> of csrc/sgo_conv4w.hpp (the default tower kernel; k_conv8w when selected) (launches with the bigger batch dominate the upper half)"}
 for k, v in per.items():
     big = sorted(v)[len(v) // 2:]          # the 8192-batch launches dominate; report their mean
     out[k] = {"launches": len(v), "mean_upper_half": sum(big) / len(big)}
