@@ -121,7 +121,7 @@ int sgo_bias_act_dev(long n_elems, int channels, const void *d_x, const void *d_
 int sgo_conv3x3_bias_act_dev(int n, int h, int w, int c, int k, int pad, const void *d_x, const void *d_w,
                              const void *d_bias, const void *d_skip, void *d_y, void *stream);
 
-/* The hand-written CDNA4 kernel for the tower shape (c = k = 256, pad 1, w <= 19; csrc/sgo_conv8w.hpp).  Same layouts. */
+/* The hand-written CDNA4 kernel for the tower shape (c = k = 256, pad 1, w <= 19; csrc/sgo_conv4w.hpp, sgo_conv8w.hpp).  Same layouts. */
 int sgo_conv3x3_tower_dev(int n, int h, int w, const void *d_x, const void *d_w, const void *d_bias, const void *d_skip,
                           void *d_y, void *stream);
 /* The hand-written CDNA4 kernel for the stem (c = 32: the 17 input planes zero-padded, k = 256, pad 0, no skip;

@@ -132,7 +132,7 @@ class FusedInferenceNet(object):
     * input NHWC fp16 with channels zero-padded 17 -> 32 (k_nn_pack layout 2), so the stem runs on an
       MFMA-friendly K instead of MIOpen's slow path for odd channel counts;
     * every 3x3 convolution of the reference's topology runs in a hand-written CDNA4 kernel of libsgo_hip.so with bias
-      (+ skip) + ReLU fused: the tower (csrc/sgo_conv8w.hpp) and the stem (csrc/sgo_stem.hpp); other channel counts
+      (+ skip) + ReLU fused: the tower (csrc/sgo_conv4w.hpp, sgo_conv8w.hpp) and the stem (csrc/sgo_stem.hpp); other channel counts
       (small test nets) fall back to the framework's convolution + ONE hand-written epilogue pass (k_bias_act);
     * both 1x1 head convolutions are one [n*t*t, C] x [C, 4] GEMM on the channels-last view.
     """
