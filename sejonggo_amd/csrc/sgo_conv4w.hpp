@@ -36,8 +36,9 @@ typedef int intx4 __attribute__((ext_vector_type(4)));
 
 constexpr int CIN = 256, COUT = 256, CT = 128;   // CT: output channels per workgroup
 constexpr int ROWB = CIN * 2, WROWB = 9 * CIN * 2, MAXW = 19;
-// LDS map: window (320 rows x 128 B), two weight buffers (128 rows x 128 B), zero area
-constexpr int LW = 0, LB0 = 40960, LB1 = 57344, LZ = 73728, LZ_BYTES = 3 * 2048 + 256, LDS_BYTES = LZ + LZ_BYTES;
+// LDS map: two weight buffers (128 rows x 128 B; first, so that every weight fragment address is one base register + a 16-bit
+// immediate: 6 VGPRs less), window (320 rows x 128 B), zero area
+constexpr int LB0 = 0, LB1 = 16384, LW = 32768, LZ = 73728, LZ_BYTES = 3 * 2048 + 256, LDS_BYTES = LZ + LZ_BYTES;
 
 #define S4_DS_READ64(dst, addr, OFF) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory")
 #define S4_DS_READ128(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory")
@@ -59,7 +60,11 @@ constexpr int LW = 0, LB0 = 40960, LB1 = 57344, LZ = 73728, LZ_BYTES = 3 * 2048 
 //   land), prefetching bias + skip rows into dead LDS behind the last K-tile's MFMAs (-2 %), staging weights[t+2] right after
 //   barrier 1 instead of behind phase A's MFMAs (-7 %: whatever sits between a barrier and the MFMA burst is exposed, what
 //   follows the burst runs in its shadow), a fifth early window piece for W >= 15 (-1.3 %), s_setprio 3 (-1.9 %), window
-//   staging unrolled with v_med3 clamps, 8 instead of ~20 instructions per piece (+-0: instruction issue is not the limit).
+//   staging unrolled with v_med3 clamps, 8 instead of ~20 instructions per piece (+-0), the next phase's fragment addresses
+//   computed inside the MFMA burst, one VALU instruction behind each MFMA (sched_group_barrier; -1.5 %), refilling fragment
+//   registers that die inside a burst right there (chan-hi of the next K-tile, K-half 0 of the next phase's pixels; -6 %).
+//   What DOES matter is the ORDER of the fragment reads: the two K-halves of a row (addresses a, a ^ 64: complementary LDS
+//   banks) back to back, as S4_READ_A issues them, is 5 % faster than all K-half-0 reads followed by all K-half-1 reads.
 template <bool HAS_SKIP, int VAR>
 __global__ __launch_bounds__(256, 2) void k_conv4w(const char *__restrict__ xb, const char *__restrict__ wb,
                                                     const _Float16 *__restrict__ bias, const char *__restrict__ skipb,
@@ -90,7 +95,6 @@ __global__ __launch_bounds__(256, 2) void k_conv4w(const char *__restrict__ xb, 
     // weight staging: instruction i of this wave fills rows (wid*2+i)*8 + (lane>>3) of a 64-row granule; 16-B chunk (lane&7)
     // of row r holds logical chunk (lane&7) ^ ((r>>1)&7)
     const int boff00 = (wid * 16 + (lane >> 3)) * WROWB + (((lane & 7) ^ (lane >> 4)) << 4);
-    const int wsrc = ((lane & 7) ^ ((lane >> 3) & 7)) << 4;
     const int fragB = (((lane >> 4) ^ ((lane >> 1) & 7)) << 4);
     const int rdB0 = (wc * 32 + (lane & 15)) * 128 + fragB, rdB1 = rdB0 ^ 64;
     const int rowA = HALO + wr * 64 + (lane & 15);
@@ -129,7 +133,8 @@ __global__ __launch_bounds__(256, 2) void k_conv4w(const char *__restrict__ xb, 
                 asm volatile("" : "+v"(la_));                                                         \
                 int q_ = tile * 256 - HALO + id_ * 8 + (la_ >> 3);                                    \
                 q_ = q_ < 0 ? 0 : (q_ < M ? q_ : M - 1);                                              \
-                const char *src_ = xb + (unsigned)(q_ * ROWB + (ccoff_) + wsrc);                      \
+                const int wsrc_ = ((la_ & 7) ^ ((la_ >> 3) & 7)) << 4;   /* recomputed: not worth a register across the loop */ \
+                const char *src_ = xb + (unsigned)(q_ * ROWB + (ccoff_) + wsrc_);                     \
                 S4_GLDS(src_, LW + id_ * 1024);                                                       \
             }                                                                                         \
         }                                                                                             \

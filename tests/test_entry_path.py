@@ -434,10 +434,11 @@ def test_distributed_selfplay_gathers_tuples_to_rank0(tmp_path, world, backend):
 @pytest.mark.gpu
 def test_bench_stdout_is_one_json_line():
     """The driver reads ONE JSON line from bench.py's stdout: whatever libraries print from C (RCCL's banner) must not land
-    there.  Small configuration (9x9, the real 256-channel tower so the roofline object names the tower kernel)."""
+    there.  Small configuration (9x9, the real 256-channel tower with enough launches for the 1-in-16 sampled
+    launch timing, so the roofline object names the tower kernel)."""
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--size", "9", "--games", "64", "--sims", "16", "--blocks", "2",
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--size", "9", "--games", "64", "--sims", "64", "--blocks", "4",
                         "--steps", "1", "--warmup", "1", "--cpu-baseline", "0", "--saturated", "0", "--steady-state", "0"],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
