@@ -62,7 +62,9 @@ constexpr int LB0 = 0, LB1 = 16384, LW = 32768, LZ = 73728, LZ_BYTES = 3 * 2048 
 //   follows the burst runs in its shadow), a fifth early window piece for W >= 15 (-1.3 %), s_setprio 3 (-1.9 %), window
 //   staging unrolled with v_med3 clamps, 8 instead of ~20 instructions per piece (+-0), the next phase's fragment addresses
 //   computed inside the MFMA burst, one VALU instruction behind each MFMA (sched_group_barrier; -1.5 %), refilling fragment
-//   registers that die inside a burst right there (chan-hi of the next K-tile, K-half 0 of the next phase's pixels; -6 %).
+//   registers that die inside a burst right there (chan-hi of the next K-tile + K-half 0 of the next phase's pixels: -6 %; the
+//   same with the burst's last quadrant pixel-tile-outer so that whole rows are refilled, 6 / 2 instead of 16 / 8 exposed reads
+//   per phase: -5.6 %, and hipcc renames the accumulators and spills at the chunk boundaries).
 //   What DOES matter is the ORDER of the fragment reads: the two K-halves of a row (addresses a, a ^ 64: complementary LDS
 //   banks) back to back, as S4_READ_A issues them, is 5 % faster than all K-half-0 reads followed by all K-half-1 reads.
 template <bool HAS_SKIP, int VAR>
