@@ -278,8 +278,9 @@ __global__ __launch_bounds__(512) void k_conv8w(const char *__restrict__ xb, con
 #pragma unroll
             for (int e = 0; e < 2; e++) {
                 const int p = tile * 256 + g * 128 + wr * 64 + (h2 * 2 + e) * 16 + (lane & 15);
-                const int q = p - (int)__umulhi((unsigned)p, magicHW) * HW;
-                const int yy = (int)__umulhi((unsigned)q, magicW), xx = q - yy * W;
+                // (a divisor of 1 has no 32-bit magic number -- ceil(2^32 / 1) wraps to 0 -- so x / 1 is added back by hand)
+                const int q = p - (int)(__umulhi((unsigned)p, magicHW) + (HW == 1 ? (unsigned)p : 0u)) * HW;
+                const int yy = (int)(__umulhi((unsigned)q, magicW) + (W == 1 ? (unsigned)q : 0u)), xx = q - yy * W;
                 const int cm = (xx >= 1 ? 1 : 0) | 2 | (xx <= W - 2 ? 4 : 0);
                 int m = (yy >= 1 ? cm : 0) | (cm << 3) | (yy <= H - 2 ? cm << 6 : 0);
                 m = p < M ? m : 0;

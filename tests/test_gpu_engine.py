@@ -810,7 +810,8 @@ def test_tower_conv_kernel(L, tower_kernel):
     torch.manual_seed(1)
     st = torch.cuda.current_stream().cuda_stream
     for (n, h, wd, with_skip) in [(1, 7, 7, True), (1, 17, 17, False), (3, 17, 17, True), (5, 17, 17, True), (5, 17, 17, False),
-                                  (64, 7, 7, True), (7, 5, 19, True), (2, 19, 19, False), (333, 17, 17, True), (1024, 17, 17, True)]:
+                                  (64, 7, 7, True), (7, 5, 19, True), (2, 19, 19, False), (333, 17, 17, True), (1024, 17, 17, True),
+                                  (300, 11, 1, False), (9, 1, 1, True), (40, 1, 13, True), (77, 2, 2, False)]:   # degenerate boards: a divisor of 1
         x = (torch.randn(n, h, wd, 256, device="cuda") * 0.5).half()
         w = (torch.randn(256, 3, 3, 256, device="cuda") * 0.03).half()
         b = torch.randn(256, device="cuda").half()
