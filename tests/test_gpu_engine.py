@@ -606,6 +606,51 @@ def test_other_sizes_and_energies_equal_the_oracle(L, S, sims, E, nm):
     eng.close()
 
 
+@pytest.mark.parametrize("seed", [101, 102, 103, 104, 105, 106, 107, 108])
+def test_fuzzed_configurations_equal_the_oracle(L, seed):
+    """Randomly drawn configurations (board size, simulations not divisible by the energy, energies 1..32, exploration
+    cut-off, komi, self-play with Dirichlet noise or evaluation mode, per-game resign thresholds, stub net): every move,
+    board, prior vector, value, result and the final tree must equal the oracle's, byte for byte."""
+    from oracle import oracle as ora
+    from sejonggo_amd.engine import SelfPlayEngine
+    from sejonggo_amd.stub_nets import make_stub
+    rng = np.random.RandomState(seed)
+    S = int(rng.choice([5, 5, 7, 9, 9, 13]))
+    E = int(rng.choice([1, 2, 4, 8, 16, 32]))
+    sims = E * int(rng.randint(2, 7)) + int(rng.randint(0, E))
+    nm = int(rng.randint(4, {5: 40, 7: 24, 9: 16, 13: 8}[S]))
+    stop = int(rng.randint(0, nm + 1))
+    komi = float(rng.choice([0.5, 5.5, 7.5]))
+    self_play = bool(rng.randint(0, 2))
+    net = make_stub(str(rng.choice(["hash", "uniform"])), S)
+    G = 8
+    noises = rng.dirichlet([0.03] * (S * S + 1), size=G)
+    uni = rng.random_sample((G, nm))
+    resign = [None if rng.rand() < 0.5 else float(rng.uniform(-1, 1)) for _ in range(G)]
+    eng = SelfPlayEngine(net, size=S, n_games=G, sims=sims, energy=E, stop_exploration=stop, num_moves=nm, komi=komi,
+                         symmetry="identity", self_play=self_play)
+    eng.start_games(np.arange(G), noises=noises if self_play else None, uniforms=uni, resign=resign)
+    games = {gd["slot"]: gd for gd in eng.run()}
+    res = eng.results()
+    cfg = (S, E, sims, nm, stop, komi, self_play)
+    for s in range(G):
+        g = ora.Game(S, sims, E, stop, nm, self_play=self_play, komi=komi, uniforms=uni[s],
+                     noises=noises[s:s + 1] if self_play else None, resign=resign[s]).run(net)
+        r = g.result()
+        assert r["end_reason"] == res[s]["end_reason"] and g.n_moves == res[s]["n_moves"], (cfg, s)
+        assert r["winner"] == res[s]["winner"] and r["black"] == res[s]["black"] and r["white"] == res[s]["white"], (cfg, s)
+        moves = games[s]["moves"] if s in games else []
+        assert len(moves) == g.n_moves, (cfg, s)
+        for i, mv in enumerate(moves):
+            m = g.move(i)
+            assert np.array_equal(mv["board"], m["board"]) and mv["policy"].tobytes() == m["policy"].tobytes(), (cfg, s, i)
+            assert mv["player"] == m["player"] and mv["value"].tobytes() == m["value"].tobytes(), (cfg, s, i)
+        ta, na, _ = eng.tree_serialize(s)
+        tb, nb, _ = g.tree_serialize()
+        assert na == nb and ta.tobytes() == tb.tobytes(), (cfg, s)
+    eng.close()
+
+
 def test_worker_survives_a_slot_that_outgrows_its_block_pool(L, tmp_path, monkeypatch):
     """With a deliberately tiny block pool some games fail with SGO_ERR_CAPACITY: the worker body must discard exactly
     those games (loudly), keep the others, and terminate."""
