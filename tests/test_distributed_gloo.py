@@ -74,11 +74,11 @@ def test_rccl_one_rank_on_the_device(tmp_path):
 
 def test_external_launcher_rendezvous_over_tcp(tmp_path):
     """The driver's way: `python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 --master-port P script`.
-    No SGO_RDZV_FILE in the environment, so init_from_env must take the launcher's MASTER_ADDR / MASTER_PORT."""
+    No SGO_RDZV_PORT in the environment, so init_from_env must take the launcher's MASTER_ADDR / MASTER_PORT."""
     import subprocess
     from sejonggo_amd.distributed import free_port
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
-    env.pop("SGO_RDZV_FILE", None)
+    env.pop("SGO_RDZV_PORT", None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.join(HERE, "dist_worker.py"), "gloo", str(tmp_path)]
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
