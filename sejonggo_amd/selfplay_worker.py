@@ -232,6 +232,12 @@ class _GpuWorker(Process):
             conf.update(snap)
         if pq._factory is None and getattr(self, '_factory_snapshot', None) is not None:
             pq.set_model_factory(self._factory_snapshot)
+        # several workers share the host's cores (one per GPU): one OpenMP thread per core in EACH of them makes the small
+        # host-side tensor ops of a step crawl (distributed.launch_ranks measures the same effect)
+        workers = max(1, int(conf.get('N_GAME_PROCESS', 1)))
+        if workers > 1:
+            import torch
+            torch.set_num_threads(max(1, (os.cpu_count() or 1) // workers))
 
 
 class NoModelSelfPlayWorker(_GpuWorker):
