@@ -313,3 +313,74 @@ def test_legacy_helpers_on_the_gpu(sync_env):
         sw.destroy_simulation_workers()
         pq.set_model_factory(None)
         pq.destroy_predicting_workers([0])
+
+
+@pytest.mark.parametrize("seed", [201, 202, 203, 204, 205, 206])
+def test_fuzzed_two_model_games_device_equals_host(sync_env, seed, monkeypatch):
+    """Two-model games inside k_search against the host dict-tree game loop (itself pinned by the reference's two-model
+    goldens) on randomly drawn configurations: board size, energy, simulations, exploration cut-off with injected draws,
+    either model moving first, a resign threshold per model.  Moves, values, policy targets, result and per-model
+    evaluation counts must agree exactly."""
+    from sejonggo_amd import nomodel_self_play as ns, play, predicting_queue_worker as pq
+    from sejonggo_amd.engine import SelfPlayEngine
+    from sejonggo_amd.stub_nets import make_stub
+    rng = np.random.RandomState(seed)
+    S = int(rng.choice([5, 7, 9]))
+    E = int(rng.choice([1, 2, 4, 8, 16]))
+    sims = E * int(rng.randint(2, 6)) + int(rng.randint(0, E))
+    nm = int(rng.randint(4, {5: 30, 7: 18, 9: 12}[S]))
+    stop = int(rng.choice([0, 0, rng.randint(1, nm + 1)]))
+    first_draw = float(rng.rand())
+    r1 = None if rng.rand() < 0.4 else float(rng.uniform(-1, 0.5))
+    r2 = None if rng.rand() < 0.4 else float(rng.uniform(-1, 0.5))
+    uni = rng.random_sample(nm)
+    nets = {"BEST": make_stub("hash", S), "LATEST": make_stub("hash2", S)}
+    cfg = (S, E, sims, nm, stop, first_draw, r1, r2)
+    # device
+    eng = SelfPlayEngine(nets["BEST"], net2=nets["LATEST"], size=S, n_games=1, sims=sims, energy=E, stop_exploration=stop,
+                         num_moves=nm, komi=5.5, symmetry="identity")
+    eng.start_eval_games([0], first_model=[0 if first_draw < .5 else 1], uniforms=uni[None, :], resign_model1=r1, resign_model2=r2)
+    dev = eng.run()
+    n_dev = list(eng.n_model_positions)
+    eng.close()
+    # host
+    sync_env.update({'SIZE': S, 'MCTS_SIMULATIONS': sims, 'ENERGY': E, 'KOMI': 5.5, 'COMPAT_LATEST_SYM': False,
+                     'COMPAT_WINNER_MODEL': True})
+    seen = {"BEST": 0, "LATEST": 0}
+
+    class Counting(object):
+        def __init__(self, kind):
+            self.kind, self.name, self.numpy_native = kind, nets[kind].name, True
+
+        def predict_on_batch(self, X):
+            seen[self.kind] += len(X)
+            return nets[self.kind].predict_on_batch(X)
+
+    wrapped = {k: Counting(k) for k in nets}
+    pq.set_model_factory(lambda kind: wrapped[kind])
+    pq.init_predicting_workers([0])
+    draws = list(uni)
+
+    def fake_choice(moves, size=1, p=None):
+        cdf = np.cumsum(np.asarray(p, dtype=np.float64))
+        cdf /= cdf[-1]
+        return [moves[int(np.searchsorted(cdf, draws.pop(0), side="right"))]]
+
+    monkeypatch.setattr(np.random, "choice", fake_choice)
+    monkeypatch.setattr(play, "random", lambda: first_draw)
+    try:
+        gd = ns.play_game_async("BEST_SYM", "LATEST_SYM", E, stop, 0, num_moves=nm, resign_model1=r1, resign_model2=r2)
+    finally:
+        pq.set_model_factory(None)
+        pq.destroy_predicting_workers([0])
+    d = dev[0] if dev else {"moves": [], "result": None}
+    assert len(d["moves"]) == len(gd["moves"]), cfg
+    for i, (a, b) in enumerate(zip(d["moves"], gd["moves"])):
+        assert tuple(a["move"]) == tuple(b["move"]) and a["player"] == b["player"], (cfg, i)
+        assert np.float32(a["value"]).tobytes() == np.float32(b["value"]).tobytes(), (cfg, i)
+        assert np.asarray(a["policy"]).tobytes() == np.asarray(b["policy"]).tobytes(), (cfg, i)
+    if gd["moves"]:
+        assert d["result"] == gd["result"] and d["winner"] == gd["winner"], cfg
+        assert d["modelB_name"] == gd["modelB_name"] and d["modelW_name"] == gd["modelW_name"], cfg
+        assert (d["winner_model"] or "") == (gd["winner_model"] or ""), cfg
+    assert n_dev == [seen["BEST"], seen["LATEST"]], cfg
