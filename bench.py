@@ -61,6 +61,7 @@ def parse():
     ap.add_argument("--steady-state", type=int, default=1, help="also measure run_selfplay-style operation with slot turnover")
     ap.add_argument("--steady-moves", type=int, default=5, help="num_moves cap of the steady-state games (short, so slots turn over)")
     ap.add_argument("--steady-generations", type=int, default=2, help="games per slot in the steady-state leg")
+    ap.add_argument("--writer-processes", type=int, default=0, help="steady-state leg: conf['WRITER_PROCESSES'] (0 = writer threads)")
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--cpu-games", type=int, default=32, help="concurrent games of the CPU baseline (the reference's N_GAME_PROCESS, conf.py:30)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="wall-clock budget of the CPU baseline sample")
@@ -163,6 +164,7 @@ def steady_state(args, net, S, G, sims, E, device, resident_value):
     try:
         conf.update(SIZE=S, MCTS_SIMULATIONS=sims, ENERGY=E, GAMES_PER_GPU=G, N_GAMES=G * gens, SELF_PLAY_DIR=tmp,
                     STOP_EXPLORATION=30, SYMMETRY_MODE=args.symmetry,
+                    WRITER_PROCESSES=args.writer_processes,
                     RESIGNATION_PERCENT=1.0)    # never resign: every game plays its `cap` plies (a random net resigns at move 0)
         pq.set_model_factory(lambda kind: net)
         played = run_selfplay(device, "BEST_SYM", n_games=G * gens, games_per_gpu=G, engine_kwargs={"num_moves": cap, "seed": 4321},
@@ -180,7 +182,7 @@ def steady_state(args, net, S, G, sims, E, device, resident_value):
             "host_seconds": {"stepping (engine + net, incl. per-step record drain)": stats["step"],
                              "turnover on the stepping thread (results, game_data, restart batch)": stats["turnover"],
                              "waiting for the writer threads after the last step": stats["writer_wait"]},
-            "writer_threads": int(keep.get('WRITER_THREADS', 2)),
+            "writer_threads": int(keep.get('WRITER_THREADS', 2)), "writer_processes": args.writer_processes,
             "note": "games start from the empty board and are capped at %d plies, so slots turn over every %d steps -- far more "
                     "often than full-length games would (~300 plies); the network cost per position is the same (%d evaluations)"
                     % (cap, cap, (sims // E) * E + 1)}

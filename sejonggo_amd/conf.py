@@ -38,6 +38,7 @@ conf = {
     'NET_DTYPE': 'fp16',
     'SYMMETRY_MODE': 'random1',  # 'random1' = reference behaviour (symmetry.py:127-132); 'avg8' = 8-fold averaging
     'WRITER_THREADS': 2,         # sample-file writer threads per self-play worker (off the stepping thread)
+    'WRITER_PROCESSES': 0,       # > 0: that many torch-free writer PROCESSES instead (own libhdf5 each; for small boards)
     'NET_CHANNELS': 256,         # filters of the tower (model.py:58 hard-codes 256)
     'COMPAT_Z': True,            # reproduce sgfsave.py:56 value_target quirk
     'COMPAT_LATEST_SYM': True,   # reproduce predicting_queue_worker.py:92: LATEST_SYM requests are answered by the BEST model

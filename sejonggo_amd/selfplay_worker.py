@@ -108,7 +108,19 @@ def run_selfplay(gpu_id, model_indicator="BEST_SYM", n_games=None, games_per_gpu
     eng = SelfPlayEngine(net, **kw)
     slot_game, slot_resign = {}, {}
     t = {"step": 0.0, "turnover": 0.0, "writer_wait": 0.0, "steps": 0, "moves": 0, "games": 0, "files": 0}
-    writers = ThreadPoolExecutor(max_workers=max(1, int(conf.get('WRITER_THREADS', 2))))
+    # Finished games leave the stepping thread at once.  Default: conf['WRITER_THREADS'] threads of this process (libhdf5
+    # is not thread-safe, so the file writes themselves are serialised on its lock: ~4-8 k files/s on the GPU box, plenty at
+    # 19x19 / 400 sims).  conf['WRITER_PROCESSES'] > 0 hands the games to that many 'spawn'ed torch-free writer processes
+    # instead, each with its own libhdf5 -- for small boards, where one GPU produces more positions than one lock writes.
+    n_proc = int(conf.get('WRITER_PROCESSES', 0) or 0)
+    if n_proc > 0 and on_game is None and not conf.get('SGF_ENABLED'):
+        from concurrent.futures import ProcessPoolExecutor
+        from .sgfsave import write_packed_game
+        writers = ProcessPoolExecutor(max_workers=n_proc, mp_context=multiprocessing.get_context('spawn'))
+        conf_items = {k: conf[k] for k in ('SELF_PLAY_DIR', 'COMPAT_Z', 'WRITE_NPZ_TWIN') if k in conf}
+    else:
+        n_proc = 0
+        writers = ThreadPoolExecutor(max_workers=max(1, int(conf.get('WRITER_THREADS', 2))))
     pending = []
 
     def write(g, gd):
@@ -116,6 +128,14 @@ def run_selfplay(gpu_id, model_indicator="BEST_SYM", n_games=None, games_per_gpu
         if on_game is not None:
             on_game(g, gd)
         return len(gd['moves'])
+
+    def submit(g, gd):
+        if n_proc:
+            mv = gd['moves']
+            return writers.submit(write_packed_game, conf_items, model_name, g, conf['SIZE'],
+                                  np.stack([m['packed'] for m in mv]), np.stack([np.asarray(m['policy'], dtype=np.float32) for m in mv]),
+                                  np.array([m['player'] for m in mv]), np.array([m['move_n'] for m in mv]), gd['winner'])
+        return writers.submit(write, g, gd)
 
     def reap(block=False):
         keep = []
@@ -180,7 +200,7 @@ def run_selfplay(gpu_id, model_indicator="BEST_SYM", n_games=None, games_per_gpu
                     if len(gd['moves']) == 0:
                         sched.discard(g)
                     else:
-                        pending.append(writers.submit(write, g, gd))
+                        pending.append(submit(g, gd))
                         played += 1
                         t["moves"] += len(gd['moves'])
                     free.append(s)

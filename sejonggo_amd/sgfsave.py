@@ -86,6 +86,22 @@ def save_self_play_data(model_name, game_no, game_data):
         save_game_sgf(model_name, game_no, game_data)
 
 
+def write_packed_game(conf_items, model_name, game_no, size, packed, policies, players, move_ns, winner):
+    """The sample files of one self-play game from its PACKED move records (768-byte positions; what a writer PROCESS
+    receives: a few hundred KB per game instead of 24.5 KB board tensors per move).  Top-level and torch-free so that a
+    'spawn'ed writer process can import and run it; `conf_items` carries the caller's conf entries the writer reads."""
+    from .engine import unpack_positions
+    if conf_items:
+        conf.update(conf_items)
+    boards = unpack_positions(packed, size)
+    for i in range(len(move_ns)):
+        directory, game_no = _make_move_dir(conf['SELF_PLAY_DIR'], model_name, "game_%05d", game_no, int(move_ns[i]))
+        vt = value_target(winner, int(players[i]), int(move_ns[i]))
+        _write_sample_arrays(directory, boards[i:i + 1].astype(np.float32), np.asarray(policies[i], dtype=np.float32),
+                             np.array(vt, dtype=np.float32))
+    return len(move_ns)
+
+
 def save_file(model_name, game_n, move_data, winner, game_name="game"):
     """sgfsave.py:16-38: one move of an evaluation / plain game under conf['GAMES_DIR']."""
     directory, _ = _make_move_dir(conf['GAMES_DIR'], model_name, game_name + "_%03d", game_n, move_data['move_n'])

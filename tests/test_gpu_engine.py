@@ -546,6 +546,46 @@ def test_selfplay_worker_body_writes_samples(L, tmp_path):
         conf.update(keep)
 
 
+def test_writer_processes_write_the_same_files_as_writer_threads(L, tmp_path):
+    """conf['WRITER_PROCESSES']: finished games go to spawned torch-free writer processes as packed records; same seeds, same
+    games, so every sample file must hold the same three arrays as the writer-thread run's."""
+    import os
+    from sejonggo_amd import predicting_queue_worker as pq
+    from sejonggo_amd.conf import conf
+    from sejonggo_amd.selfplay_worker import run_selfplay
+    from sejonggo_amd.stub_nets import make_stub
+    from tests.helpers import read_sample
+    keep = dict(conf)
+    net = make_stub("hash", 9)
+    out = {}
+    try:
+        for mode, procs in (("threads", 0), ("procs", 2)):
+            conf.update({'SIZE': 9, 'MCTS_SIMULATIONS': 16, 'ENERGY': 8, 'STOP_EXPLORATION': 0, 'N_GAMES': 6, 'NUM_MOVES': 7,
+                         'SELF_PLAY_DIR': str(tmp_path / mode), 'GAMES_PER_GPU': 3, 'WRITER_PROCESSES': procs,
+                         'RESIGNATION_PERCENT': 1.0})
+            pq.set_model_factory(lambda kind: net)
+            stats = {}
+            played = run_selfplay(0, "BEST", n_games=6, games_per_gpu=3, max_steps=400, stats=stats,
+                                  engine_kwargs={'num_moves': 7, 'dirichlet_epsilon': 0.0})
+            assert played == 6 and stats["files"] == stats["moves"] == 42
+            files = {}
+            root = os.path.join(conf['SELF_PLAY_DIR'], net.name)
+            for g in sorted(os.listdir(root)):
+                for m in sorted(os.listdir(os.path.join(root, g))):
+                    files[(g, m)] = read_sample(os.path.join(root, g, m, "sample.h5"))
+            out[mode] = files
+            pq.destroy_predicting_workers([0])
+        assert out["threads"].keys() == out["procs"].keys() and len(out["procs"]) == 42
+        for k in out["threads"]:
+            for a, b in zip(out["threads"][k], out["procs"][k]):
+                assert np.asarray(a).tobytes() == np.asarray(b).tobytes(), k
+    finally:
+        pq.set_model_factory(None)
+        pq.destroy_predicting_workers([0])
+        conf.clear()
+        conf.update(keep)
+
+
 def test_tree_dict_view_equals_the_canonical_serialisation(L):
     """engine.tree_dict rebuilds the reference's nested dict nodes from the device tree; hashing that dict tree the
     way the golden harness hashes the reference's dict tree must reproduce the golden hash."""
