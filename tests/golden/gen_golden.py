@@ -920,6 +920,10 @@ ASYNC_CASES = [
     (9, 48, 8, "hash+hash2", None, 0, 10),   # model1 (BEST) moves first, whole game
     (9, 48, 8, "hash+hash2", 30, 0, 11),     # model2 (LATEST) moves first
     (5, 32, 8, "hash2+hash", None, 0, 13),   # tiny board: the other tree often lacks the played move
+    # sizes between the tested extremes, energies other than 8 (single model)
+    (13, 40, 8, "hash", 8, 3, 14),
+    (7, 36, 4, "hash", None, 5, 15),         # whole 7x7 game, 4-leaf rounds
+    (13, 33, 16, "uniform", 5, 5, 16),       # sims not divisible by the energy (32 effective), 16-leaf rounds
 ]
 
 

@@ -23,7 +23,8 @@ def name_of(z, key):
     return bytes(z[key]).decode()
 
 
-ASYNC_FILES = ["async_%02d.npz" % i for i in range(9)]   # 08 = BASELINE config 5 (19x19, 1600 sims, 32-leaf rounds)
+# 08 = BASELINE config 5 (19x19, 1600 sims, 32-leaf rounds); 09..11 are the two-model games; 12..14: 13x13 / 7x7, energies 4 / 16
+ASYNC_FILES = ["async_%02d.npz" % i for i in list(range(9)) + [12, 13, 14]]
 
 
 def dict_tree_hash(root):
