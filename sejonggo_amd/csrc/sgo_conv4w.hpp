@@ -59,8 +59,8 @@ constexpr int LB0 = 0, LB1 = 16384, LW = 32768, LZ = 73728, LZ_BYTES = 3 * 2048 
 //   dropped: refilling the weight buffer after barrier 2 so that barrier 1 disappears (-4 %: the weights get less time to
 //   land), prefetching bias + skip rows into dead LDS behind the last K-tile's MFMAs (-2 %), staging weights[t+2] right after
 //   barrier 1 instead of behind phase A's MFMAs (-7 %: whatever sits between a barrier and the MFMA burst is exposed, what
-//   follows the burst runs in its shadow), a fifth early window piece for W >= 15 (-1.3 %), s_setprio 3 (-1.9 %), the priorities the other way round (read intervals at 2
-//   or 3 above the bursts: -2.4 .. -3 %), window
+//   follows the burst runs in its shadow), a fifth early window piece for W >= 15 (-1.3 %), s_setprio 3 (-1.9 %), the
+//   priorities the other way round (read intervals at 2 or 3 above the bursts: -2.4 .. -3 %), window
 //   staging unrolled with v_med3 clamps, 8 instead of ~20 instructions per piece (+-0), the next phase's fragment addresses
 //   computed inside the MFMA burst, one VALU instruction behind each MFMA (sched_group_barrier; -1.5 %), refilling fragment
 //   registers that die inside a burst right there (chan-hi of the next K-tile + K-half 0 of the next phase's pixels: -6 %; the

@@ -257,7 +257,6 @@ __global__ __launch_bounds__(64) void k_board_advance_rows_nn(int n, const int *
                                                               uint32_t *legal, const int32_t *legal_idx, const int32_t *nn_row,
                                                               int k, _Float16 *nn_out) {
     using G = Geo<S>;
-    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
     if (n_dev) n = *n_dev;
     const int half = threadIdx.x >> 5, y = threadIdx.x & 31;
     const int i0 = blockIdx.x * 2;
