@@ -98,6 +98,8 @@ __global__ __launch_bounds__(256, 2) void k_conv4w(const char *__restrict__ xb, 
     // weight staging: instruction i of this wave fills rows (wid*2+i)*8 + (lane>>3) of a 64-row granule; 16-B chunk (lane&7)
     // of row r holds logical chunk (lane&7) ^ ((r>>1)&7)
     const int boff00 = (wid * 16 + (lane >> 3)) * WROWB + (((lane & 7) ^ (lane >> 4)) << 4);
+    int bvo0 = boff00, bvo1 = boff00 ^ 64;
+    asm volatile("" : "+v"(bvo0), "+v"(bvo1));            // opaque: two registers, never re-derived inside the loop
     const int fragB = (((lane >> 4) ^ ((lane >> 1) & 7)) << 4);
     const int rdB0 = (wc * 32 + (lane & 15)) * 128 + fragB, rdB1 = rdB0 ^ 64;
     const int rowA = HALO + wr * 64 + (lane & 15);
@@ -118,6 +120,13 @@ __global__ __launch_bounds__(256, 2) void k_conv4w(const char *__restrict__ xb, 
 // weights of the K-tile whose bytes start at koff_ of a filter row, granule G (64 filters) into buffer BUF
 #define S4_STAGE_BK(BUF, G, koff_)                                                                    \
     do {                                                                                              \
+        if (VAR & 8) {   /* lean: the per-lane part is one of two loop-invariant registers, the rest is scalar */ \
+            _Pragma("unroll") for (int i_ = 0; i_ < 2; i_++) {                                        \
+                const char *sb_ = wbh + ((i_ * 8 + (G) * 64) * WROWB + (koff_));                      \
+                S4_GLDS(sb_ + (unsigned)(i_ ? bvo1 : bvo0), ((BUF) ? LB1 : LB0) + (G) * 8192 + (swid * 2 + i_) * 1024); \
+            }                                                                                         \
+            break;                                                                                    \
+        }                                                                                             \
         int bo_ = boff00;                                                                             \
         asm volatile("" : "+v"(bo_));                                                                 \
         _Pragma("unroll") for (int i_ = 0; i_ < 2; i_++) {                                            \
@@ -160,6 +169,31 @@ __global__ __launch_bounds__(256, 2) void k_conv4w(const char *__restrict__ xb, 
             pa[mt_][1] = S4_LDS16((ok_ ? b1_ : z1_) + mt_ * 2048);                                    \
         }                                                                                             \
     } while (0)
+#define S4_READ_A_LEAN(G, T)                                                                          \
+    do {                                                                                              \
+        if ((G) == 0) {                                                                               \
+            int ra_ = rowA;                                                                           \
+            asm volatile("" : "+v"(ra_));                                                             \
+            const int rl_ = ra_ + S4_SHIFT(T);                                                        \
+            const int c0_ = (((lane >> 4) ^ rl_) & 7) << 4;                                           \
+            lb0 = LW + (rl_ << 7) + c0_;                                                              \
+            lz0 = LZ + ((rl_ & 1) << 7) + c0_;                                                        \
+        }                                                                                             \
+        const int b0_ = lb0 + (G) * 16384;                                                            \
+        int mka_ = mk[G][0], mkb_ = mk[G][1];                                                         \
+        asm volatile("" : "+v"(mka_), "+v"(mkb_));                                                    \
+        int av_[4];                                                                                   \
+        _Pragma("unroll") for (int mt_ = 0; mt_ < 4; mt_++) {                                         \
+            int m_;                                  /* m = 0 or -1; a = m ? window row : zero row (hipcc does not form these) */ \
+            asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m_) : "v"((mt_ >> 1) ? mkb_ : mka_), "n"((mt_ & 1) * 9 + (T)));       \
+            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(av_[mt_]) : "v"(m_), "v"(b0_), "v"(lz0));            \
+        }                                                                                             \
+        _Pragma("unroll") for (int mt_ = 0; mt_ < 4; mt_++) {   /* the two K-halves of a row back to back: the order matters */ \
+            __builtin_amdgcn_sched_barrier(0);                                                        \
+            pa[mt_][0] = S4_LDS16(av_[mt_] + mt_ * 2048);                                             \
+            pa[mt_][1] = S4_LDS16((av_[mt_] ^ 64) + mt_ * 2048);                                      \
+        }                                                                                             \
+    } while (0)
 #define S4_READ_B(BUF, G, dst)                                                                        \
     _Pragma("unroll") for (int nt_ = 0; nt_ < 2; nt_++) {                                             \
         dst[nt_][0] = S4_LDS16(((BUF) ? LB1 : LB0) + (G) * 8192 + nt_ * 2048 + rdB0);                 \
@@ -183,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void k_conv4w(const char *__restrict__ xb, 
         S4_READ_B(BUF_, 0, wlo);                                                                          \
         S4_READ_B(BUF_, 1, whi);                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                \
-        S4_READ_A(0, T);                                                                                  \
+        if (VAR & 8) { S4_READ_A_LEAN(0, T); } else { S4_READ_A(0, T); }                                  \
         S4_LGKM0();                                                                                       \
         /* barrier 1: every wave has read weights[t] (its buffer may be refilled) and, in the last tap, the window rows */ \
         /* [0, 128) for the last time */                                                                  \
@@ -200,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void k_conv4w(const char *__restrict__ xb, 
             S4_VMWAIT(0);                        /* early pieces); the late pieces, issued a whole phase ago, are needed from here */ \
             S4_BARRIER();                                                                                 \
         }                                                                                                 \
-        S4_READ_A(1, T);                                                                                  \
+        if (VAR & 8) { S4_READ_A_LEAN(1, T); } else { S4_READ_A(1, T); }                                  \
         if (!last2_) {                                                                                    \
             const int koff_ = T2_ * (CIN * 2) + (cc + CARRY_) * 128;                                      \
             S4_STAGE_BK(BUF_, 0, koff_);                                                                  \
@@ -231,6 +265,7 @@ __global__ __launch_bounds__(256, 2) void k_conv4w(const char *__restrict__ xb, 
         }                                                                                                 \
     } while (0)
 
+    int lb0 = 0, lz0 = 0;   // (lean variant) window / zero-area address of the current tap, shared by a K-tile's two phases
     // late window pieces (pc 4..9) this wave issues at a chunk boundary: the counted wait there depends on it
     int nlate = 0;
 #pragma unroll
@@ -405,6 +440,7 @@ static inline int launch(int n, int h, int w, const void *x, const void *wgt, co
     case 4: return launch_var<4>(n, h, w, x, wgt, bias, skip, y, st);
     case 5: return launch_var<5>(n, h, w, x, wgt, bias, skip, y, st);
     case 6: return launch_var<6>(n, h, w, x, wgt, bias, skip, y, st);
+    case 15: return launch_var<15>(n, h, w, x, wgt, bias, skip, y, st);
 #endif
     default: return launch_var<7>(n, h, w, x, wgt, bias, skip, y, st);
     }
