@@ -66,6 +66,9 @@ constexpr int LB0 = 0, LB1 = 16384, LW = 32768, LZ = 73728, LZ_BYTES = 3 * 2048 
 //   registers that die inside a burst right there (chan-hi of the next K-tile + K-half 0 of the next phase's pixels: -6 %; the
 //   same with the burst's last quadrant pixel-tile-outer so that whole rows are refilled, 6 / 2 instead of 16 / 8 exposed reads
 //   per phase: -5.6 %, and hipcc renames the accumulators and spills at the chunk boundaries).
+//   A leaner instruction stream (v_bfe / v_bfi mask select, phase B reusing phase A's row address, scalar weight-staging
+//   addresses: 37 instead of 60 VALU per K-tile) ran 3.5 % SLOWER: differences of this size are inside the band that code
+//   placement alone moves a hipcc-built kernel by (guide rule 27), so nothing below ~3 % is claimed as a schedule effect.
 //   What DOES matter is the ORDER of the fragment reads: the two K-halves of a row (addresses a, a ^ 64: complementary LDS
 //   banks) back to back, as S4_READ_A issues them, is 5 % faster than all K-half-0 reads followed by all K-half-1 reads.
 template <bool HAS_SKIP, int VAR>
@@ -98,8 +101,6 @@ __global__ __launch_bounds__(256, 2) void k_conv4w(const char *__restrict__ xb, 
     // weight staging: instruction i of this wave fills rows (wid*2+i)*8 + (lane>>3) of a 64-row granule; 16-B chunk (lane&7)
     // of row r holds logical chunk (lane&7) ^ ((r>>1)&7)
     const int boff00 = (wid * 16 + (lane >> 3)) * WROWB + (((lane & 7) ^ (lane >> 4)) << 4);
-    int bvo0 = boff00, bvo1 = boff00 ^ 64;
-    asm volatile("" : "+v"(bvo0), "+v"(bvo1));            // opaque: two registers, never re-derived inside the loop
     const int fragB = (((lane >> 4) ^ ((lane >> 1) & 7)) << 4);
     const int rdB0 = (wc * 32 + (lane & 15)) * 128 + fragB, rdB1 = rdB0 ^ 64;
     const int rowA = HALO + wr * 64 + (lane & 15);
@@ -120,13 +121,6 @@ __global__ __launch_bounds__(256, 2) void k_conv4w(const char *__restrict__ xb, 
 // weights of the K-tile whose bytes start at koff_ of a filter row, granule G (64 filters) into buffer BUF
 #define S4_STAGE_BK(BUF, G, koff_)                                                                    \
     do {                                                                                              \
-        if (VAR & 8) {   /* lean: the per-lane part is one of two loop-invariant registers, the rest is scalar */ \
-            _Pragma("unroll") for (int i_ = 0; i_ < 2; i_++) {                                        \
-                const char *sb_ = wbh + ((i_ * 8 + (G) * 64) * WROWB + (koff_));                      \
-                S4_GLDS(sb_ + (unsigned)(i_ ? bvo1 : bvo0), ((BUF) ? LB1 : LB0) + (G) * 8192 + (swid * 2 + i_) * 1024); \
-            }                                                                                         \
-            break;                                                                                    \
-        }                                                                                             \
         int bo_ = boff00;                                                                             \
         asm volatile("" : "+v"(bo_));                                                                 \
         _Pragma("unroll") for (int i_ = 0; i_ < 2; i_++) {                                            \
@@ -169,31 +163,6 @@ __global__ __launch_bounds__(256, 2) void k_conv4w(const char *__restrict__ xb, 
             pa[mt_][1] = S4_LDS16((ok_ ? b1_ : z1_) + mt_ * 2048);                                    \
         }                                                                                             \
     } while (0)
-#define S4_READ_A_LEAN(G, T)                                                                          \
-    do {                                                                                              \
-        if ((G) == 0) {                                                                               \
-            int ra_ = rowA;                                                                           \
-            asm volatile("" : "+v"(ra_));                                                             \
-            const int rl_ = ra_ + S4_SHIFT(T);                                                        \
-            const int c0_ = (((lane >> 4) ^ rl_) & 7) << 4;                                           \
-            lb0 = LW + (rl_ << 7) + c0_;                                                              \
-            lz0 = LZ + ((rl_ & 1) << 7) + c0_;                                                        \
-        }                                                                                             \
-        const int b0_ = lb0 + (G) * 16384;                                                            \
-        int mka_ = mk[G][0], mkb_ = mk[G][1];                                                         \
-        asm volatile("" : "+v"(mka_), "+v"(mkb_));                                                    \
-        int av_[4];                                                                                   \
-        _Pragma("unroll") for (int mt_ = 0; mt_ < 4; mt_++) {                                         \
-            int m_;                                  /* m = 0 or -1; a = m ? window row : zero row (hipcc does not form these) */ \
-            asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m_) : "v"((mt_ >> 1) ? mkb_ : mka_), "n"((mt_ & 1) * 9 + (T)));       \
-            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(av_[mt_]) : "v"(m_), "v"(b0_), "v"(lz0));            \
-        }                                                                                             \
-        _Pragma("unroll") for (int mt_ = 0; mt_ < 4; mt_++) {   /* the two K-halves of a row back to back: the order matters */ \
-            __builtin_amdgcn_sched_barrier(0);                                                        \
-            pa[mt_][0] = S4_LDS16(av_[mt_] + mt_ * 2048);                                             \
-            pa[mt_][1] = S4_LDS16((av_[mt_] ^ 64) + mt_ * 2048);                                      \
-        }                                                                                             \
-    } while (0)
 #define S4_READ_B(BUF, G, dst)                                                                        \
     _Pragma("unroll") for (int nt_ = 0; nt_ < 2; nt_++) {                                             \
         dst[nt_][0] = S4_LDS16(((BUF) ? LB1 : LB0) + (G) * 8192 + nt_ * 2048 + rdB0);                 \
@@ -217,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void k_conv4w(const char *__restrict__ xb, 
         S4_READ_B(BUF_, 0, wlo);                                                                          \
         S4_READ_B(BUF_, 1, whi);                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                \
-        if (VAR & 8) { S4_READ_A_LEAN(0, T); } else { S4_READ_A(0, T); }                                  \
+        S4_READ_A(0, T);                                                                                  \
         S4_LGKM0();                                                                                       \
         /* barrier 1: every wave has read weights[t] (its buffer may be refilled) and, in the last tap, the window rows */ \
         /* [0, 128) for the last time */                                                                  \
@@ -234,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void k_conv4w(const char *__restrict__ xb, 
             S4_VMWAIT(0);                        /* early pieces); the late pieces, issued a whole phase ago, are needed from here */ \
             S4_BARRIER();                                                                                 \
         }                                                                                                 \
-        if (VAR & 8) { S4_READ_A_LEAN(1, T); } else { S4_READ_A(1, T); }                                  \
+        S4_READ_A(1, T);                                                                                  \
         if (!last2_) {                                                                                    \
             const int koff_ = T2_ * (CIN * 2) + (cc + CARRY_) * 128;                                      \
             S4_STAGE_BK(BUF_, 0, koff_);                                                                  \
@@ -265,7 +234,6 @@ __global__ __launch_bounds__(256, 2) void k_conv4w(const char *__restrict__ xb, 
         }                                                                                                 \
     } while (0)
 
-    int lb0 = 0, lz0 = 0;   // (lean variant) window / zero-area address of the current tap, shared by a K-tile's two phases
     // late window pieces (pc 4..9) this wave issues at a chunk boundary: the counted wait there depends on it
     int nlate = 0;
 #pragma unroll
@@ -440,7 +408,6 @@ static inline int launch(int n, int h, int w, const void *x, const void *wgt, co
     case 4: return launch_var<4>(n, h, w, x, wgt, bias, skip, y, st);
     case 5: return launch_var<5>(n, h, w, x, wgt, bias, skip, y, st);
     case 6: return launch_var<6>(n, h, w, x, wgt, bias, skip, y, st);
-    case 15: return launch_var<15>(n, h, w, x, wgt, bias, skip, y, st);
 #endif
     default: return launch_var<7>(n, h, w, x, wgt, bias, skip, y, st);
     }
