@@ -151,7 +151,7 @@ typedef struct sgo_config {
     int32_t energy;           /* conf['ENERGY'] (<= 64) */
     int32_t stop_exploration; /* conf['STOP_EXPLORATION'] */
     int32_t num_moves;        /* play_game_async(num_moves); <0 => 2*S*S */
-    int32_t blocks_per_game;  /* tree-block pool per game; <=0 => 10*sims + 64 */
+    int32_t blocks_per_game;  /* tree-block pool per game; <=0 => 20*sims + 128, bounded by the LDS work queue and by 60 % of the free device memory */
     int32_t self_play;        /* add Dirichlet noise when a tree is created (play.py:400-403) */
     double komi;              /* conf['KOMI'] */
     double dirichlet_epsilon; /* conf['DIRICHLET_EPSILON'] */

@@ -37,6 +37,7 @@ conf = {
     'GAMES_PER_GPU': 1024,       # concurrent game slots resident on one MI355X
     'NET_DTYPE': 'fp16',
     'SYMMETRY_MODE': 'random1',  # 'random1' = reference behaviour (symmetry.py:127-132); 'avg8' = 8-fold averaging
+    'BLOCKS_PER_GAME': 0,        # tree blocks per resident game; 0 = the engine's default (20 * sims + 128, memory permitting)
     'WRITER_THREADS': 2,         # sample-file writer threads per self-play worker (off the stepping thread)
     'WRITER_PROCESSES': 0,       # > 0: that many torch-free writer PROCESSES instead (own libhdf5 each; for small boards)
     'NET_CHANNELS': 256,         # filters of the tower (model.py:58 hard-codes 256)

@@ -879,7 +879,25 @@ sgo_ctx *sgo_ctx_create(const sgo_config *cfg) {
     if (c.cfg.two_model && c.cfg.self_play) { set_error("sgo_ctx_create: two_model games are not self-play games"); delete x; return nullptr; }
     c.S = cfg->size; c.A = c.S * c.S + 1; c.NW = sgo_plane_words(c.S); c.RW = sgo_packed_words(c.S);
     c.APAD = 32 * c.NW; c.G = cfg->n_games; c.E = cfg->energy;
-    c.cap = cfg->blocks_per_game > 0 ? cfg->blocks_per_game : 10 * cfg->sims + 64;
+    if (cfg->blocks_per_game > 0) {
+        c.cap = cfg->blocks_per_game;
+    } else {
+        // Default pool: 20 sims + 128 blocks per game.  A search adds <= sims blocks and a move keeps the chosen child's subtree,
+        // so a tree settles at sims / (1 - f) blocks, f = the share of the visits under the chosen child: late in a game, with
+        // argmax moves, f passes 0.9 -- with 10 sims + 64 (round 1's default) 32 of 256 full-length 19x19 / 400-sim games ran out
+        // of blocks and were discarded, with 20 sims + 128 none (tools/stress_selfplay.py).  Bounded by the k_search work queue in
+        // LDS and by 60 % of the device memory that is free now (BASELINE config 5: 1 024 games x 1 600 sims).
+        long want = 20L * cfg->sims + 128;
+        const long lds_max = (160L * 1024 / 4 - 2L * c.APAD - 4) * 32 / 33 - 32;
+        if (want > lds_max) want = lds_max;
+        const size_t per_block = sizeof(uint32_t) * ((size_t)c.RW + c.NW) + (size_t)c.APAD * (4 * 5 + 1) + 3 * sizeof(int32_t);
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) {
+            const long fit = (long)(free_b / 10 * 6 / ((size_t)c.G * per_block));
+            if (want > fit) want = fit;
+        }
+        c.cap = (int)want;
+    }
     if (c.cap < cfg->energy + 2) c.cap = cfg->energy + 2;
     c.max_moves = cfg->num_moves < 0 ? 2 * c.S * c.S : cfg->num_moves;
     c.rec_cap = 2 * c.G + 16;

@@ -103,7 +103,7 @@ def run_selfplay(gpu_id, model_indicator="BEST_SYM", n_games=None, games_per_gpu
     sym = conf.get('SYMMETRY_MODE', 'random1') if model_indicator.endswith("_SYM") else "identity"
     kw = dict(size=conf['SIZE'], n_games=G, sims=conf['MCTS_SIMULATIONS'], energy=conf['ENERGY'],
               stop_exploration=conf['STOP_EXPLORATION'], komi=conf['KOMI'], self_play=True, symmetry=sym,
-              device=gpu_id, seed=gpu_id, raise_on_error=False)
+              device=gpu_id, seed=gpu_id, raise_on_error=False, blocks_per_game=int(conf.get('BLOCKS_PER_GAME', 0) or 0))
     kw.update(engine_kwargs or {})
     eng = SelfPlayEngine(net, **kw)
     slot_game, slot_resign = {}, {}

@@ -180,7 +180,7 @@ def test_full_length_19x19_games_equal_the_oracle(L):
 
 def test_config5_search_width_equals_the_oracle(L):
     """BASELINE config 5's workload -- 19x19, 1 600 sims per move in rounds of 32 leaves (conf.py:18,29) -- with the
-    default block pool (10 * sims + 64 = 16 064 blocks per game, k_search's > 64 KiB dynamic-LDS path): two concurrent
+    default block pool (20 * sims + 128 = 32 128 blocks per game, k_search's > 64 KiB dynamic-LDS path): two concurrent
     games, two plies, every move, policy target, whole tree and root table equal to the oracle's."""
     from sejonggo_amd.engine import SelfPlayEngine
     from sejonggo_amd.stub_nets import make_stub

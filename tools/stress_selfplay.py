@@ -19,6 +19,8 @@ def main():
     ap.add_argument("--blocks", type=int, default=4)
     ap.add_argument("--channels", type=int, default=64)
     ap.add_argument("--stop", type=int, default=30)
+    ap.add_argument("--blocks-per-game", type=int, default=0, help="tree blocks per game (0 = the engine's default)")
+    ap.add_argument("--no-resign", type=int, default=0, help="1: RESIGNATION_PERCENT = 1 (every game runs to its natural end)")
     a = ap.parse_args()
     import numpy as np
     from sejonggo_amd import predicting_queue_worker as pq
@@ -28,13 +30,37 @@ def main():
     d = tempfile.mkdtemp(prefix="sgo_stress_")
     conf.update({'SIZE': a.size, 'MCTS_SIMULATIONS': a.sims, 'ENERGY': 8, 'STOP_EXPLORATION': a.stop, 'SELF_PLAY_DIR': d,
                  'GAMES_PER_GPU': a.resident})
+    if a.no_resign:
+        conf['RESIGNATION_PERCENT'] = 1.0
     fnet, _ = build_fused_net(a.size, a.blocks, a.channels, name="stress")
     pq.set_model_factory(lambda kind: fnet)
     lens, results = [], []
     t0 = time.time()
-    played = run_selfplay(0, "BEST_SYM", n_games=a.games, games_per_gpu=a.resident,
-                          on_game=lambda g, gd: (lens.append(len(gd['moves'])), results.append(gd['result'] + " " + gd['end_reason'])))
+    stats = {}
+    last = [t0]
+
+    def on_game(g, gd):
+        lens.append(len(gd['moves']))
+        results.append(gd['result'] + " " + gd['end_reason'])
+        if time.time() - last[0] > 30:          # a progress line at least every 30 s (gpurun takes a silent run for hung)
+            last[0] = time.time()
+            print("  %d games done after %.0f s" % (len(lens), time.time() - t0), flush=True)
+
+    import threading
+    stop = threading.Event()
+
+    def heartbeat():
+        while not stop.wait(45):
+            print("  ... %.0f s, %d games done" % (time.time() - t0, len(lens)), flush=True)
+
+    hb = threading.Thread(target=heartbeat, daemon=True)
+    hb.start()
+    played = run_selfplay(0, "BEST_SYM", n_games=a.games, games_per_gpu=a.resident, on_game=on_game, stats=stats,
+                          engine_kwargs={'blocks_per_game': a.blocks_per_game})
+    stop.set()
     dt = time.time() - t0
+    print("engine steps %d; slots that failed and were discarded: %d of %d started" % (
+        stats.get("steps", -1), a.games - played if a.games >= played else 0, a.games))
     lens = np.array(lens)
     print("played %d games in %.1f s: %d positions, %.1f positions/s; length min/mean/max %d/%.1f/%d" % (
         played, dt, lens.sum(), lens.sum() / dt, lens.min(), lens.mean(), lens.max()))
