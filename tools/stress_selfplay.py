@@ -20,6 +20,9 @@ def main():
     ap.add_argument("--channels", type=int, default=64)
     ap.add_argument("--stop", type=int, default=30)
     ap.add_argument("--blocks-per-game", type=int, default=0, help="tree blocks per game (0 = the engine's default)")
+    ap.add_argument("--policy-gain", type=float, default=1.0,
+                    help="multiply the policy head's last layer: > 1 makes a random-init net's priors peaky, like a trained net's "
+                         "(concentrated search -> the kept subtree holds most of the tree -> the block pool is stressed)")
     ap.add_argument("--no-resign", type=int, default=0, help="1: RESIGNATION_PERCENT = 1 (every game runs to its natural end)")
     a = ap.parse_args()
     import numpy as np
@@ -32,7 +35,22 @@ def main():
                  'GAMES_PER_GPU': a.resident})
     if a.no_resign:
         conf['RESIGNATION_PERCENT'] = 1.0
-    fnet, _ = build_fused_net(a.size, a.blocks, a.channels, name="stress")
+    if a.policy_gain != 1.0:
+        import torch
+        from sejonggo_amd.net import FusedInferenceNet, PolicyValueNet
+        torch.manual_seed(0)
+        plain = PolicyValueNet(a.size, a.blocks, a.channels, name="stress")
+        for mod in plain.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.running_mean.normal_(0, 0.1)
+                mod.running_var.uniform_(0.5, 1.5)
+        plain.eval()
+        with torch.no_grad():
+            plain.p_fc.weight.mul_(a.policy_gain)
+        fnet = FusedInferenceNet(plain, torch.float16, "cuda")
+        fnet.name = "stress"
+    else:
+        fnet, _ = build_fused_net(a.size, a.blocks, a.channels, name="stress")
     pq.set_model_factory(lambda kind: fnet)
     lens, results = [], []
     t0 = time.time()
