@@ -171,20 +171,32 @@ struct Eng {
         return (c.legal[(gb0 + blk) * G::NW + (i >> 5)] >> (i & 31)) & 1u;
     }
 
-    // play.py:308-323 on block `blk`; returns chosen slot or -1
-    __device__ int top_one(int blk, bool f64) const {
+    // play.py:308-323 on block `blk`; returns chosen slot or -1, and in `child` the chosen slot's child block (-1: a leaf).
+    // Every array of the block is loaded UNCONDITIONALLY for all slots (expand() initialises all APAD slots, illegal ones with
+    // zeros), so that the ~30 loads of a node are in flight together: one memory round trip per tree level instead of four
+    // (legal word -> N / busy under that mask -> P / Q under the not-busy mask -> the winner's child pointer), which is what a
+    // descent through a late-game tree spent its time on (k_search averaged 0.9 ms per call over a full 19x19 game, 0.2 ms at
+    // the first plies).
+    __device__ int top_one(int blk, bool f64, int &child) const {
         const size_t sb = slot_base(blk);
-        int n_[G::APAD / 64 + 1];
-        int sum = 0;
         constexpr int J = (G::APAD + 63) / 64;
+        int n_[J], cb_[J];
+        float p_[J], q_[J];
         bool ex[J], busy[J];
+        int sum = 0;
 #pragma unroll
         for (int j = 0; j < J; j++) {
-            int i = lane + 64 * j;
-            bool in = i < G::APAD;
-            ex[j] = in && legal_bit(blk, in ? i : 0);
-            n_[j] = ex[j] ? c.cN[sb + i] : 0;
-            busy[j] = ex[j] ? (c.cBusy[sb + i] > 0) : true;
+            const int i = lane + 64 * j;
+            const bool in = i < G::APAD;
+            const uint32_t lw = in ? c.legal[(gb0 + blk) * G::NW + (i >> 5)] : 0u;
+            const int nv = in ? c.cN[sb + i] : 0;
+            const int bz = in ? (int)c.cBusy[sb + i] : 1;
+            p_[j] = in ? c.cP[sb + i] : 0.f;
+            q_[j] = in ? c.cQ[sb + i] : 0.f;
+            cb_[j] = in ? c.cB[sb + i] : -1;
+            ex[j] = in && ((lw >> (i & 31)) & 1u);
+            n_[j] = ex[j] ? nv : 0;
+            busy[j] = ex[j] ? (bz > 0) : true;
             sum += n_[j];
         }
         sum = wave_sum_i(sum);
@@ -198,9 +210,9 @@ struct Eng {
             for (int j = 0; j < J; j++) {
                 int i = lane + 64 * j;
                 if (!busy[j]) {
-                    float u = c.cP[sb + i] * tnf;
+                    float u = p_[j] * tnf;
                     u = u / (float)(1.0 + (double)n_[j]);
-                    float v = c.cQ[sb + i] + u;
+                    float v = q_[j] + u;
                     if (v > bs) { bs = v; best = i; }
                 }
             }
@@ -213,12 +225,20 @@ struct Eng {
                 int i = lane + 64 * j;
                 if (!busy[j]) {
                     double u = p64[i] * tn / (1. + (double)n_[j]);
-                    double v = (double)c.cQ[sb + i] + u;
+                    double v = (double)q_[j] + u;
                     if (v > bs) { bs = v; best = i; }
                 }
             }
             wave_argmax<double>(bs, best);
         }
+        int cb = -1;
+        if (best >= 0) {
+#pragma unroll
+            for (int j = 0; j < J; j++)
+                if ((best >> 6) == j) cb = cb_[j];
+            cb = __shfl(cb, best & 63);
+        }
+        child = cb;
         return best;
     }
 
@@ -226,7 +246,8 @@ struct Eng {
     __device__ bool find_best_leaf(const GameState &st, int &pblk, int &slot) const {
         int node = st.root_blk;
         for (;;) {
-            int a = top_one(node, st.root_f64 && node == st.root_blk);
+            int cb = -1;
+            int a = top_one(node, st.root_f64 && node == st.root_blk, cb);
             if (a < 0) {
                 int par = c.bParent[gb0 + node];
                 if (par < 0) return false;
@@ -235,9 +256,6 @@ struct Eng {
                 node = par;
                 continue;
             }
-            int cb = 0;
-            if (lane == (a & 63)) cb = c.cB[slot_base(node) + a];
-            cb = __shfl(cb, a & 63);
             if (cb < 0) {
                 if (lane == (a & 63)) c.cBusy[slot_base(node) + a] = 2;
                 pblk = node;
@@ -290,16 +308,11 @@ struct Eng {
             leaf_value = w;
         }
         leaf_value = __shfl(leaf_value, slot & 63);
-        int node = pb;
-        for (;;) {
-            int par = c.bParent[gb0 + node];
-            if (par < 0) {
-                st.root_count += 1;
-                st.root_value += leaf_value;
-                st.root_mean = st.root_value / (float)st.root_count;
-                break;
-            }
-            int ps = c.bSlot[gb0 + node];
+        // Walk to the root.  One memory round trip per level: the next level's parent / slot are requested together with this
+        // level's statistics (the walk was three dependent round trips per level: parent, then slot, then N / W).
+        int par = c.bParent[gb0 + pb], ps = c.bSlot[gb0 + pb];
+        while (par >= 0) {
+            const int npar = c.bParent[gb0 + par], nps = c.bSlot[gb0 + par];
             if (lane == (ps & 63)) {
                 const size_t o = slot_base(par) + ps;
                 int n = c.cN[o] + 1;
@@ -309,8 +322,12 @@ struct Eng {
                 c.cQ[o] = w / (float)n;
                 c.cBusy[o] = 0;
             }
-            node = par;
+            par = npar;
+            ps = nps;
         }
+        st.root_count += 1;
+        st.root_value += leaf_value;
+        st.root_mean = st.root_value / (float)st.root_count;
     }
 };
 
@@ -530,29 +547,39 @@ __global__ __launch_bounds__(64) void k_search(Ctx c, const float *policy, const
                 c.bParent[e.gb0 + nr] = -1; c.bSlot[e.gb0 + nr] = -1;
                 if (onr >= 0) { c.bParent[e.gb0 + onr] = -1; c.bSlot[e.gb0 + onr] = -1; }
             }
-            // mark: BFS over expanded nodes (of both trees)
-            for (int i = lane; i < (c.cap + 31) / 32; i += 64) marks[i] = 0;
-            if (lane == 0) { queue[0] = nr; if (onr >= 0) queue[1] = onr; }
+            // mark: which blocks hang below the new root(s)?  Every allocated block is linked from its parent exactly once (the
+            // graft in back_propagate) and carries that parent in bParent, so "reachable from the new root" = "the parent chain
+            // ends in it".  All chains are resolved together by pointer jumping on a copy of the parent array in LDS:
+            // O(log depth) passes of cap / 64 coalesced steps, instead of a breadth-first walk that paid one dependent memory
+            // round trip per CHILD ARRAY of every kept block (22 ms for a late-game tree, measured; now tens of microseconds).
+            constexpr int KEEP = -3, DROP = -4;
+            int *par = queue;
+            for (int b = lane; b < c.cap; b += 64) {
+                const int pv = c.bParent[e.gb0 + b];
+                par[b] = pv < 0 ? DROP : pv;                       // other roots (the old one): dropped
+            }
             __syncthreads();
-            int head = 0, tail = onr >= 0 ? 2 : 1;
-            while (head < tail) {
-                const int b = queue[head++];
-                const size_t bsb = e.slot_base(b);
-                for (int j0 = 0; j0 < G::APAD; j0 += 64) {
-                    int i = j0 + lane;
-                    int cb = (i < G::APAD && e.legal_bit(b, i)) ? c.cB[bsb + i] : -1;
-                    unsigned long long m = __ballot(cb >= 0);
-                    if (cb >= 0) queue[tail + __popcll(m & ((1ull << lane) - 1ull))] = cb;
-                    tail += __popcll(m);
+            for (int i = lane; i < st.free_top; i += 64) par[c.freeList[(size_t)g * c.cap + i]] = DROP;   // stale parents of free blocks
+            __syncthreads();
+            if (lane == 0) { par[nr] = KEEP; if (onr >= 0) par[onr] = KEEP; }
+            __syncthreads();
+            for (;;) {
+                bool open = false;
+                for (int b = lane; b < c.cap; b += 64) {
+                    const int pv = par[b];
+                    if (pv >= 0) {
+                        const int pp = par[pv];                    // KEEP / DROP resolve b; otherwise jump to the grandparent
+                        par[b] = pp;
+                        open |= pp >= 0;
+                    }
                 }
                 __syncthreads();
+                if (!__any(open)) break;
             }
-            for (int i = lane; i < tail; i += 64) atomicOr(&marks[queue[i] >> 5], 1u << (queue[i] & 31));
-            __syncthreads();
             int ft = 0;
             for (int b0 = 0; b0 < c.cap; b0 += 64) {
                 int b = b0 + lane;
-                bool fr = b < c.cap && !((marks[b >> 5] >> (b & 31)) & 1u);
+                bool fr = b < c.cap && par[b] != KEEP;
                 unsigned long long m = __ballot(fr);
                 if (fr) c.freeList[(size_t)g * c.cap + ft + __popcll(m & ((1ull << lane) - 1ull))] = b;
                 ft += __popcll(m);

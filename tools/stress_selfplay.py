@@ -77,6 +77,8 @@ def main():
                           engine_kwargs={'blocks_per_game': a.blocks_per_game})
     stop.set()
     dt = time.time() - t0
+    print("host seconds: stepping %.1f, turnover %.1f, waiting for writers at the end %.1f" % (
+        stats.get("step", 0), stats.get("turnover", 0), stats.get("writer_wait", 0)))
     print("engine steps %d; slots that failed and were discarded: %d of %d started" % (
         stats.get("steps", -1), a.games - played if a.games >= played else 0, a.games))
     lens = np.array(lens)
