@@ -199,6 +199,23 @@ struct Eng {
             busy[j] = ex[j] ? (bz > 0) : true;
             sum += n_[j];
         }
+        // A position whose only legal move is the pass (the endgame's pass-pass chains, hundreds of levels deep: the reference's
+        // search has no terminal test) needs no scores: its single child is chosen unless it is busy -- what the general path
+        // below computes too (any finite score beats -100), minus two wave reductions and the score arithmetic.
+        {
+            constexpr int jN = G::N >> 6, lN = G::N & 63;
+            bool only_pass = true;
+#pragma unroll
+            for (int j = 0; j < J; j++) {
+                const unsigned long long m = __ballot(ex[j]);
+                only_pass = only_pass && (m == (j == jN ? (1ull << lN) : 0ull));
+            }
+            if (only_pass) {
+                const int bz = __shfl((int)busy[jN], lN);
+                child = bz ? -1 : __shfl(cb_[jN], lN);
+                return bz ? -1 : G::N;
+            }
+        }
         sum = wave_sum_i(sum);
         double tn = sqrt((double)sum);
         if (tn == 0) tn = 1;
