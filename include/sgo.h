@@ -243,6 +243,10 @@ int64_t sgo_tree_dump(sgo_ctx *ctx, int slot, uint8_t *buf, int64_t cap, int64_t
 int sgo_game_board(sgo_ctx *ctx, int slot, int32_t *board17);
 /* test hook: stop slot right before the move choice of move_n == k (phase becomes done, error 0) */
 int sgo_set_halt(sgo_ctx *ctx, int slot, int move_n);
+/* Diagnostic: cycles per phase of k_search, summed over games and calls (zeros unless the library was built with
+ * -DSGO_KSEARCH_PROFILE): [0] consuming evaluations, [2] selection, [7] round back-propagation, [3] move step, [4] wave-calls. */
+int sgo_debug_counters(sgo_ctx *ctx, unsigned long long *out, int n);
+
 /* average duration (ms) and launch count of the board_advance kernel inside sgo_step since the last
  * call (HIP events on the step's stream); used by bench.py for the roofline object */
 int sgo_advance_timing(sgo_ctx *ctx, double *total_ms, int64_t *launches, int64_t *positions);

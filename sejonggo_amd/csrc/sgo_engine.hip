@@ -63,6 +63,7 @@ struct Counters {
     int32_t rec_count;
     int32_t pad;
     unsigned long long total_moves, total_evals, none_events;
+    unsigned long long dbg[8];   // diagnostic build (-DSGO_KSEARCH_PROFILE): cycles per phase of k_search, summed over games
 };
 
 struct DevStatus {  // written by k_compact, copied to the host once per step
@@ -291,12 +292,31 @@ struct Eng {
     __device__ void expand(int blk, const float *policy, const int32_t *lut, const double *noise, double eps) const {
         const size_t sb = slot_base(blk);
         double *p64 = c.rootP64 + (size_t)g * G::APAD;
-        for (int i = lane; i < G::APAD; i += 64) {
-            bool ex = legal_bit(blk, i);
-            float p = (ex && i < G::A) ? policy[lut[i]] : 0.0f;
+        // all loads of the node first (legal words, the symmetry LUT, then the gathered priors: two dependent round trips for the
+        // whole node), then the stores: the slot-by-slot loop paid three dependent round trips per 64 slots -- 43 % of k_search
+        constexpr int J = (G::APAD + 63) / 64;
+        bool ex[J];
+        int src[J];
+        float pr[J];
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+            const int i = lane + 64 * j;
+            ex[j] = i < G::APAD && legal_bit(blk, i < G::APAD ? i : 0);
+            src[j] = i < G::A ? lut[i] : 0;
+        }
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+            const int i = lane + 64 * j;
+            pr[j] = i < G::A ? policy[src[j]] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+            const int i = lane + 64 * j;
+            if (i >= G::APAD) continue;
+            float p = (ex[j] && i < G::A) ? pr[j] : 0.0f;
             if (noise) {
                 double t = (1.0 - eps) * (double)p;
-                double pd = ex ? t + eps * noise[i] : 0.0;
+                double pd = ex[j] ? t + eps * noise[i] : 0.0;
                 p64[i] = pd;
                 p = (float)pd;
             }
@@ -397,6 +417,12 @@ __global__ __launch_bounds__(64) void k_search(Ctx c, const float *policy, const
     };
 
     // ---- consume the evaluations requested by the previous step
+#ifdef SGO_KSEARCH_PROFILE
+    long long tq0 = clock64(), tq1;
+#define SGO_TICK(k) do { tq1 = clock64(); if (lane == 0) atomicAdd(&c.counters->dbg[k], (unsigned long long)(tq1 - tq0)); tq0 = tq1; } while (0)
+#else
+#define SGO_TICK(k) do { } while (0)
+#endif
     if (st.phase == PH_WAIT_ROOT) {
         if (!st.root_requested) {
             st.root_requested = 1;
@@ -466,7 +492,9 @@ __global__ __launch_bounds__(64) void k_search(Ctx c, const float *policy, const
     }
 
     // ---- async_simulate2 rounds (nomodel_self_play.py:59-82) until evaluations are needed
+    SGO_TICK(0);
     while (run && st.phase == PH_SEARCH) {
+        SGO_TICK(7);
         if (st.rounds_left == 0) {
             // ================= select_play tail + play_game_async body (:125-138, :180-216)
             if (st.halt_at == st.move_n) { st.phase = PH_DONE; run = false; break; }
@@ -641,6 +669,7 @@ __global__ __launch_bounds__(64) void k_search(Ctx c, const float *policy, const
             break;
         }
         if (st.e_left < 0) { st.e_left = c.cfg.energy; st.pre_bp = 0; }
+        SGO_TICK(1);
         bool blocked = false;
         int resume = -1;                         // parent of the leaf selected last in this round; -1 = walk from the root
         while (st.e_left > 0) {
@@ -680,6 +709,7 @@ __global__ __launch_bounds__(64) void k_search(Ctx c, const float *policy, const
             st.req_kind = 1;
             st.e_left--;
         }
+        SGO_TICK(2);
         __syncthreads();
         if (!run || blocked) break;
         bool pending = false;
@@ -697,6 +727,10 @@ __global__ __launch_bounds__(64) void k_search(Ctx c, const float *policy, const
         st.e_left = -1;
         st.rounds_left--;
     }
+    SGO_TICK(3);
+#ifdef SGO_KSEARCH_PROFILE
+    if (lane == 0) atomicAdd(&c.counters->dbg[4], 1ull);
+#endif
     if (lane == 0) c.gs[g] = st;
 }
 
@@ -1295,6 +1329,16 @@ int sgo_game_board(sgo_ctx *x, int slot, int32_t *board17) {
     }
     (void)hipFree(d);
     return r;
+}
+
+/* Diagnostic: cycles per phase of k_search summed over games and calls (zeros unless built with -DSGO_KSEARCH_PROFILE):
+ * [0] consuming evaluations (expand), [2] selection, [7] the round's back-propagation, [3] the move step, [4] wave-calls. */
+int sgo_debug_counters(sgo_ctx *x, unsigned long long *out, int n) {
+    if (!x || !out || n < 0) return SGO_ERR_ARG;
+    Counters h;
+    SGO_HIP(hipMemcpy(&h, x->c.counters, sizeof h, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n && i < 8; i++) out[i] = h.dbg[i];
+    return SGO_OK;
 }
 
 int sgo_advance_timing(sgo_ctx *x, double *total_ms, int64_t *launches, int64_t *positions) {

@@ -71,6 +71,37 @@ def main():
         while not stop.wait(45):
             print("  ... %.0f s, %d games done" % (time.time() - t0, len(lens)), flush=True)
 
+    # diagnostic library (-DSGO_KSEARCH_PROFILE): cycles per phase of k_search, read every few seconds through the engine's context
+    import ctypes as C
+    from sejonggo_amd import engine as eng_mod
+    real_engine = eng_mod.SelfPlayEngine
+    probe = {}
+
+    class Probed(real_engine):
+        def __init__(self, *aa, **kk):
+            real_engine.__init__(self, *aa, **kk)
+            probe["eng"] = self
+
+        def step(self):
+            st = real_engine.step(self)
+            n = probe["n"] = probe.get("n", 0) + 1
+            if n % 2550 == 0:                    # every 50 moves
+                out = (C.c_ulonglong * 8)()
+                self.lib.sgo_debug_counters(self.ctx, out, 8)
+                cur = [int(v) for v in out]
+                prev = probe.get("prev", [0] * 8)
+                d = [a - b for a, b in zip(cur, prev)]
+                probe["prev"] = cur
+                if any(d):
+                    tot = float(sum(d[i] for i in (0, 2, 3, 7))) or 1.0
+                    print("  k_search cycles, moves %d-%d: consume %.0f%%, select %.0f%%, round back-propagation %.0f%%, move step + exit %.0f%%; "
+                          "%.0f cycles per wave-call" % (n // 51 - 50, n // 51, 100 * d[0] / tot, 100 * d[2] / tot, 100 * d[7] / tot,
+                                                        100 * d[3] / tot, tot / max(d[4], 1)), flush=True)
+            return st
+
+    eng_mod.SelfPlayEngine = Probed
+    import sejonggo_amd.selfplay_worker as sw_mod
+
     hb = threading.Thread(target=heartbeat, daemon=True)
     hb.start()
     played = run_selfplay(0, "BEST_SYM", n_games=a.games, games_per_gpu=a.resident, on_game=on_game, stats=stats,
