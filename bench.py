@@ -62,6 +62,8 @@ def parse():
     ap.add_argument("--steady-moves", type=int, default=5, help="num_moves cap of the steady-state games (short, so slots turn over)")
     ap.add_argument("--steady-generations", type=int, default=2, help="games per slot in the steady-state leg")
     ap.add_argument("--writer-processes", type=int, default=0, help="steady-state leg: conf['WRITER_PROCESSES'] (0 = writer threads)")
+    ap.add_argument("--avg8-leg", type=int, default=1, help="headline configuration only: one warm-up + one step with 8-fold symmetry "
+                    "averaging (BASELINE config 3 as written), reported as config3_avg8")
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--cpu-games", type=int, default=32, help="concurrent games of the CPU baseline (the reference's N_GAME_PROCESS, conf.py:30)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="wall-clock budget of the CPU baseline sample")
@@ -188,6 +190,51 @@ def steady_state(args, net, S, G, sims, E, device, resident_value):
                     % (cap, cap, (sims // E) * E + 1)}
 
 
+def avg8_leg(net, S, G, sims, E, device, steps=1, warmup=1):
+    """BASELINE config 3 as written -- "+ 8-fold symmetry averaging" (a build extension: the reference applies ONE random
+    symmetry per batch, symmetry.py:127-132, which is what the headline `value` runs): every evaluation list goes through the
+    net under all 8 symmetries, the policies are inverse-permuted and averaged in float32.  Same games, sims and net."""
+    import numpy as np
+    import torch
+    from sejonggo_amd.engine import SelfPlayEngine
+    eng = SelfPlayEngine(net, size=S, n_games=G, sims=sims, energy=E, stop_exploration=30, symmetry="avg8", device=device, seed=4242)
+    eng.start_games(np.arange(G))
+
+    def one_step():
+        target = eng.status.total_moves + G
+        while eng.status.total_moves < target:
+            if eng.step().n_active < G:
+                raise RuntimeError("a game ended inside the avg8 leg")
+        eng.drain()
+        for s in range(G):
+            eng.records[s] = []
+
+    try:
+        for _ in range(warmup):
+            one_step()
+        timed = hasattr(net, "conv_events")
+        if timed:
+            net.conv_events, net.side_flops, net.conv_event_stride = [], 0.0, 1
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one_step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out = {"value": G * steps / dt, "unit": "positions/sec", "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * dt / steps,
+               "symmetry": "avg8", "net_evals_per_position": 8 * ((sims // E) * E + 1)}
+        if timed:
+            evs, net.conv_events = net.conv_events, None
+            ms = sum(e0.elapsed_time(e1) for e0, e1, _ in evs)
+            fl = sum(f for _, _, f in evs)
+            if ms > 0:
+                out["roofline"] = {"bound": "mfma", "achieved": fl / (ms * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
+                                   "frac": fl / (ms * 1e-3) / 1e12 / 2500.0, "launches": len(evs), "share_of_step_time": ms * 1e-3 / dt}
+        return out
+    finally:
+        eng.close()
+
+
 def saturated_advance(S, n=1 << 18, ply=60, iters=10):
     """board_advance through the dense C-ABI entry point on a batch large enough to fill the chip (the in-situ
     launch holds only games*energy leaves).  Positions come from seeded random legal playouts on the GPU."""
@@ -279,7 +326,7 @@ def run_rank(args):
     from sejonggo_amd.engine import SelfPlayEngine
     from sejonggo_amd.net import build_net, build_fused_net
     from sejonggo_amd.stub_nets import make_stub
-    from sejonggo_amd.distributed import tuple_dtype, gather_tuples
+    from sejonggo_amd.distributed import tuple_dtype, TupleGather, device_identities
     S, G, sims, E = args.size, args.games, args.sims, args.energy
     if args.tower_kernel >= 0:
         from sejonggo_amd import _lib as _L
@@ -301,6 +348,9 @@ def run_rank(args):
                          device=local, seed=1234 + rank)
     eng.start_games(np.arange(G))
     tdt = tuple_dtype(S)
+    exchange = TupleGather(tdt)          # side stream, per-batch staging: step k's gather overlaps the search of steps k+1, k+2
+    gathered = [0]
+    rccl = device_identities()           # which physical device every rank computes on (N ranks must show N distinct devices)
 
     def one_step():
         """every game advances one move; then this step's records are gathered to rank 0"""
@@ -320,7 +370,8 @@ def run_rank(args):
                 recs[k]["game_seq"] = mv["game_seq"]
                 k += 1
             eng.records[s] = []
-        return gather_tuples(recs[:k])
+        for got in exchange.submit(recs[:k]):
+            gathered[0] += 0 if got is None else len(got)
 
     def sync():
         dist.barrier()
@@ -340,6 +391,8 @@ def run_rank(args):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
+    for got in exchange.flush():             # the last two steps' tuples: the timed region ends with every tuple on rank 0
+        gathered[0] += 0 if got is None else len(got)
     sync()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
@@ -386,6 +439,8 @@ def run_rank(args):
                        "sharding": "games g -> rank g mod N; weights broadcast from rank 0; %s gather of per-step records to rank 0"
                                    % ("RCCL" if args.backend == "nccl" else "gloo"),
                        "backend": args.backend, "weights_broadcast": bcast},
+            "rccl": dict(rccl, tuples_on_rank0=gathered[0],
+                         gather="TupleGather: counts all_gather + padded gather to rank 0, 3-stage pipeline on a side stream"),
             "roofline_board_advance": {"bound": "hbm", "kernel": ("board_advance fused with nn_input_pack in situ (k_board_advance_rows_nn: make_play + legal set + history move + "
                                                                   "the child's fp16 NHWC-32 network-input row, one half-wavefront per leaf)" if eng.fused_pack else
                                                                   "board_advance in situ (make_play + legal set + history move of the step's leaf list; k_board_advance_rows up to 32 768 leaves, k_board_advance above)"),
@@ -436,6 +491,12 @@ def run_rank(args):
             except Exception:
                 pass
         eng.close()
+        if (args.avg8_leg and world == 1 and args.symmetry == "random1" and args.net == "resnet" and not args.plain_net
+                and (S, sims, G, args.blocks, args.channels) == (19, 400, 1024, 20, 256)):
+            try:
+                out["config3_avg8"] = avg8_leg(net, S, G, sims, E, local)
+            except Exception as ex:
+                out["config3_avg8"] = {"error": repr(ex)}
         if args.steady_state and world == 1:
             try:
                 out["steady_state"] = steady_state(args, net, S, G, sims, E, local, out["value"])

@@ -43,8 +43,14 @@ extern "C" {
 #define SGO_ERR_DRAWS (-202)      /* ran out of injected random draws */
 #define SGO_ERR_STATE (-203)      /* call sequence violated */
 
+/* Bumped whenever a signature or a struct layout below changes.  A binding compares it with sgo_version() of the
+ * library it loaded and refuses a mismatch (sejonggo_amd/_lib.py load(); INTEGRATION.md §B does the same).
+ *   1: round 1.   2: sgo_start_games(+stream), sgo_game_result.first_model (40 bytes), sgo_config.two_model,
+ *   sgo_conv_backend removed.   3: this round's additions (see the "half-populations" and "packed stem" sections). */
+#define SGO_ABI_VERSION 3
+
 const char *sgo_last_error(void);
-int sgo_version(void);
+int sgo_version(void);            /* SGO_ABI_VERSION the library was built with */
 int sgo_device_count(void);
 int sgo_set_device(int device_id);
 

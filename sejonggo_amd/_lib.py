@@ -10,6 +10,7 @@ LIB_PATH = os.path.join(_HERE, "libsgo_hip.so")
 
 SUPPORTED_SIZES = (5, 7, 9, 13, 19)
 
+ABI_VERSION = 3          # SGO_ABI_VERSION of include/sgo.h these bindings were written against
 SGO_OK = 0
 SGO_ERR_OCCUPIED = -101
 SGO_ERR_RANGE = -102
@@ -75,6 +76,9 @@ def load():
     # the copy torch already loaded, so the engine and the net share one runtime (streams, pointers).
     import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
+    if lib.sgo_version() != ABI_VERSION:
+        raise SgoError("libsgo_hip.so speaks ABI version %d, these bindings version %d (include/sgo.h SGO_ABI_VERSION): "
+                       "rebuild with `python -m sejonggo_amd.build`" % (lib.sgo_version(), ABI_VERSION))
     lib.sgo_last_error.restype = C.c_char_p
     lib.sgo_ctx_create.restype = C.c_void_p
     lib.sgo_ctx_create.argtypes = [C.POINTER(Config)]

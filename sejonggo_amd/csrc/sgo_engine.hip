@@ -132,7 +132,7 @@ static StageLayout stage_layout(int n, int APAD, int nu, bool has_noise) {
 struct HostSide {  // not passed to kernels
     uint8_t *stage = nullptr;                  // pinned host twin of Ctx::stage
     size_t stage_cap = 0;
-    hipEvent_t ev_stage = nullptr;             // the H2D copy out of `stage` has completed
+    hipEvent_t ev_stage = nullptr;             // k_start has consumed the staged batch (host block and device twin)
     bool stage_busy = false;
     hipStream_t last_stream = nullptr;         // stream of the last sgo_step (records are drained behind it)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // bracket board_advance inside sgo_step
@@ -1066,10 +1066,12 @@ static int start_games_impl(sgo_ctx *x, int n, const int32_t *slots, const doubl
     }
     // one host-to-device copy, then one kernel, both on the caller's stream: ordered against the steps before and after
     SGO_HIP(hipMemcpyAsync(c.stage, h, L.total, hipMemcpyHostToDevice, st));
-    SGO_HIP(hipEventRecord(x->h.ev_stage, st));
-    x->h.stage_busy = true;
     SGO_DISPATCH(c.S, k_start<kS><<<dim3(n), dim3(64), 0, st>>>(c, n, L, noise != nullptr, nu > 0));
     SGO_HIP(hipGetLastError());
+    // recorded BEHIND k_start: the event guards the pinned block and its device twin `c.stage` alike, so the next batch
+    // (whatever stream it arrives on) is staged only after this one's kernel has read its slots / draws
+    SGO_HIP(hipEventRecord(x->h.ev_stage, st));
+    x->h.stage_busy = true;
     return SGO_OK;
 }
 

@@ -715,7 +715,7 @@ using namespace sgo;
 extern "C" {
 
 const char *sgo_last_error(void) { return g_err.c_str(); }
-int sgo_version(void) { return 1; }
+int sgo_version(void) { return SGO_ABI_VERSION; }
 int sgo_advance_mode(int mode) { return set_advance_mode(mode); }
 int sgo_device_count(void) {
     int n = 0;

@@ -7,7 +7,7 @@
 One process per GPU.  Game numbers shard statically (game g -> rank g mod N), every rank keeps conf['GAMES_PER_GPU'] games
 resident on its own engine with its own replica of the best model (weights broadcast from rank 0, checksums compared), and
 there is NO exchange during search.  Every `sync_every` engine steps all ranks meet in one variable-length gather
-(distributed.gather_tuples: counts all_gather + padded byte gather; 7 concurrent point-to-point transfers into rank 0 on the
+(distributed.TupleGather: counts all_gather + padded byte gather, pipelined on a side stream; 7 concurrent point-to-point transfers into rank 0 on the
 xGMI mesh) carrying the tuples of the games that finished since the last meeting, plus one all_reduce that tells everybody
 whether anyone still plays.  Rank 0 turns the tuples back into the reference's files
 (SELF_PLAY_DIR/<model>/game_%05d/move_%03d/sample.h5, sgfsave.py:49-79) on its writer threads; the other ranks never touch
@@ -69,7 +69,7 @@ def run_rank(backend="nccl", sync_every=4, max_steps=None):
     import torch.distributed as dist
     from concurrent.futures import ThreadPoolExecutor
     from .conf import conf
-    from .distributed import broadcast_net, gather_tuples, init_from_env, shard_games, tuple_dtype
+    from .distributed import TupleGather, broadcast_net, init_from_env, shard_games, tuple_dtype
     from .engine import SelfPlayEngine
     from .predicting_queue_worker import get_model, init_predicting_workers, put_name_request
     from .selfplay_worker import GameScheduler
@@ -118,6 +118,7 @@ def run_rank(backend="nccl", sync_every=4, max_steps=None):
     pending, outbox = [], []
     played = written = steps = 0
     dev = torch.device("cuda", local) if backend == "nccl" else torch.device("cpu")
+    exchange = TupleGather(tuple_dtype(S), device=dev)     # side stream + per-batch staging: a meeting's gather overlaps the next steps
     try:
         active = fill(range(G))
         idle = G - active
@@ -159,13 +160,16 @@ def run_rank(backend="nccl", sync_every=4, max_steps=None):
             # the meeting: finished games to rank 0, and does anybody still play?
             batch = np.concatenate(outbox) if outbox else np.zeros(0, dtype=tuple_dtype(S))
             outbox = []
-            got = gather_tuples(batch)
-            if rank == 0:
-                _write_games(got, model_name, S, pool, pending)
+            for got in exchange.submit(batch):               # batches of EARLIER meetings whose gather has completed
+                if rank == 0:
+                    _write_games(got, model_name, S, pool, pending)
             flag = torch.tensor([1 if active > 0 else 0], dtype=torch.int32, device=dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)
             if int(flag.item()) == 0:
                 break
+        for got in exchange.flush():
+            if rank == 0:
+                _write_games(got, model_name, S, pool, pending)
     finally:
         eng.close()
         if pool is not None:

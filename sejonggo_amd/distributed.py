@@ -3,9 +3,10 @@ search); the collectives are (1) one broadcast of the network weights from rank 
 (2) the gather of finished (s, pi, z) tuples to rank 0 (SURVEY.md §8e -- the reference ships files by scp,
 scpy.py:68-76).  Works on RCCL (backend "nccl", CUDA tensors) and on gloo (CPU tensors; the world_size-2 CPU tests).
 
-Variable-length gather: all_gather of one int64 count per rank, then dist.gather of max-padded uint8
+Variable-length gather (TupleGather): all_gather of one int64 count per rank, then dist.gather of max-padded uint8
 blocks (on the 8-GPU xGMI mesh that is 7 concurrent point-to-point transfers into rank 0, a few MB at
-most, far below one link's bandwidth), then rank 0 trims the padding.
+most, far below one link's bandwidth), then rank 0 trims the padding -- pipelined over three submits on a side stream
+with per-batch staging buffers, so the exchange of step k overlaps the search of steps k+1 and k+2.
 
 `launch_ranks` starts one fresh interpreter per rank (never a fork of a process that may hold a GPU) with the
 torch.distributed environment set; bench.py --gpus N and the tests use it."""
@@ -139,32 +140,156 @@ def _comm_device():
 
 # ---------------------------------------------------------------------------------------------- collectives
 def gather_tuples(tuples, device=None, dst=0):
-    """tuples: numpy structured array (tuple_dtype) of this rank.  Returns the concatenation over ranks on
-    rank `dst` (rank order), None elsewhere.  Without an initialised process group the input is returned; with
-    one -- world size 1 included -- the collectives run."""
-    import torch
+    """Blocking form: this rank's tuples (numpy structured array, tuple_dtype) -> the concatenation over ranks on rank
+    `dst` (rank order), None elsewhere.  Without an initialised process group the input is returned; with one -- world
+    size 1 included -- the collectives run.  The self-play loops use TupleGather below, which keeps the exchange off the
+    stepping stream; this form is one submit + flush of it."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
         return tuples
-    world, rank = dist.get_world_size(), dist.get_rank()
-    dev = device if device is not None else _comm_device()
-    itemsize = tuples.dtype.itemsize
-    cnt = torch.tensor([len(tuples)], dtype=torch.int64, device=dev)
-    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(counts, cnt)
-    counts = [int(c.item()) for c in counts]
-    mx = max(max(counts), 1)
-    buf = torch.zeros(mx * itemsize, dtype=torch.uint8, device=dev)
-    if len(tuples):
-        raw = torch.from_numpy(np.frombuffer(tuples.tobytes(), dtype=np.uint8).copy())
-        buf[:raw.numel()] = raw.to(dev)
-    if rank == dst:
-        outs = [torch.zeros_like(buf) for _ in range(world)]
-        dist.gather(buf, outs, dst=dst)
-        parts = [np.frombuffer(o.cpu().numpy().tobytes()[:c * itemsize], dtype=tuples.dtype) for o, c in zip(outs, counts)]
-        return np.concatenate(parts) if parts else tuples[:0]
-    dist.gather(buf, None, dst=dst)
-    return None
+    g = TupleGather(tuples.dtype, device=device, dst=dst)
+    g.submit(tuples)
+    out = g.flush()
+    if dist.get_rank() != dst:
+        return None
+    return out[0] if out else tuples[:0]
+
+
+class TupleGather(object):
+    """Variable-length gather of (s, pi, z) tuples to rank `dst`, OFF the critical path: every batch goes
+    through three stages, one per `submit`, all on a side stream with their own staging buffers, so the exchange of step
+    k overlaps the search of steps k+1 and k+2 and the stepping thread never waits for a collective it has just issued:
+
+      stage 1 (submit k)    payload -> pinned host block -> device block (async copy); all_gather of the per-rank counts
+      stage 2 (submit k+1)  counts read (issued one step ago: complete), blocks padded to the largest, dist.gather to dst
+      stage 3 (submit k+2)  dst: device -> pinned host copy, trimmed per rank, handed to the caller in submit order
+
+    On RCCL the gather is 7 concurrent point-to-point transfers into rank 0 over the xGMI mesh; on gloo (CPU tensors) the
+    same stages run without a stream.  `submit` returns the batches that completed (possibly none); `flush` drains."""
+
+    def __init__(self, dtype, device=None, dst=0):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.dtype = np.dtype(dtype)
+        self.dst = dst
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        self.dev = device if device is not None else _comm_device()
+        self.on_gpu = self.dev.type == "cuda"
+        self.side = torch.cuda.Stream(device=self.dev) if self.on_gpu else None
+        self.inflight = []          # batches in submit order, each a dict with its stage
+        self.n_submitted = 0
+        self.bytes_gathered = 0
+
+    # -- stages ---------------------------------------------------------------------------------------------------
+    def _stream(self):
+        import contextlib
+        return self.torch.cuda.stream(self.side) if self.on_gpu else contextlib.nullcontext()
+
+    def _stage1(self, tuples):
+        torch, dist = self.torch, self.dist
+        n = len(tuples)
+        raw = np.frombuffer(np.ascontiguousarray(tuples).tobytes(), dtype=np.uint8)
+        host = torch.empty(max(raw.size, 1), dtype=torch.uint8, pin_memory=self.on_gpu)
+        host[:raw.size].copy_(torch.from_numpy(raw.copy()))
+        b = {"n": n, "nbytes": raw.size, "stage": 1}
+        with self._stream():
+            b["payload"] = host.to(self.dev, non_blocking=True) if self.on_gpu else host
+            b["host"] = host                                            # keeps the pinned block alive until the copy has run
+            cnt = torch.tensor([n], dtype=torch.int64).to(self.dev, non_blocking=True)
+            b["counts"] = [torch.zeros(1, dtype=torch.int64, device=self.dev) for _ in range(self.world)]
+            b["work"] = dist.all_gather(b["counts"], cnt, async_op=True)
+            b["cnt"] = cnt
+        return b
+
+    def _stage2(self, b):
+        torch, dist = self.torch, self.dist
+        b["work"].wait()
+        with self._stream():
+            counts = [int(c.item()) for c in b["counts"]]                # issued a step ago: no wait worth the name
+            b["count_list"] = counts
+            width = max(max(counts), 1) * self.dtype.itemsize
+            block = torch.zeros(width, dtype=torch.uint8, device=self.dev)
+            if b["nbytes"]:
+                block[:b["nbytes"]].copy_(b["payload"][:b["nbytes"]], non_blocking=True)
+            b["block"] = block
+            if self.rank == self.dst:
+                b["outs"] = [torch.empty_like(block) for _ in range(self.world)]
+                b["work"] = dist.gather(block, b["outs"], dst=self.dst, async_op=True)
+            else:
+                b["work"] = dist.gather(block, None, dst=self.dst, async_op=True)
+        b["stage"] = 2
+
+    def _stage3(self, b):
+        torch = self.torch
+        b["work"].wait()
+        b["stage"] = 3
+        if self.rank != self.dst:
+            return None
+        with self._stream():
+            hosts = []
+            for o, c in zip(b["outs"], b["count_list"]):
+                nb = c * self.dtype.itemsize
+                h = torch.empty(max(nb, 1), dtype=torch.uint8, pin_memory=self.on_gpu)
+                if nb:
+                    h[:nb].copy_(o[:nb], non_blocking=True)
+                hosts.append((h, nb))
+            if self.on_gpu:
+                self.side.synchronize()                                  # this batch's own copies; the compute stream is not involved
+        parts = [np.frombuffer(h.numpy()[:nb].tobytes(), dtype=self.dtype) for h, nb in hosts]
+        self.bytes_gathered += sum(nb for _, nb in hosts)
+        return np.concatenate(parts) if parts else np.zeros(0, dtype=self.dtype)
+
+    # -- driver ---------------------------------------------------------------------------------------------------
+    def _advance(self, drain=False):
+        done = []
+        # oldest first, one stage per call per batch (all of them when draining); collectives are issued in the same order
+        # on every rank because every rank submits the same number of batches
+        while True:
+            moved = False
+            for b in list(self.inflight):
+                if b["stage"] == 2:
+                    done.append(self._stage3(b))
+                    self.inflight.remove(b)
+                    moved = True
+                elif b["stage"] == 1:
+                    self._stage2(b)
+                    moved = True
+            if not drain or not self.inflight or not moved:
+                break
+        return done
+
+    def submit(self, tuples):
+        """Queue this rank's batch (every rank must call submit the same number of times).  Returns the list of batches
+        that completed during the call: on `dst` the gathered arrays in submit order, elsewhere Nones."""
+        assert tuples.dtype == self.dtype
+        done = self._advance()
+        self.inflight.append(self._stage1(tuples))
+        self.n_submitted += 1
+        return done
+
+    def flush(self):
+        return self._advance(drain=True)
+
+
+def device_identities():
+    """One line per rank: which physical device the rank computes on (UUID where the runtime reports one, PCI address
+    otherwise), gathered over the process group -- a SCALE record can then show that N ranks ran on N DISTINCT devices.
+    Returns {"world", "backend", "devices": [...], "distinct"}."""
+    import torch
+    import torch.distributed as dist
+    me = "cpu"
+    if torch.cuda.is_available():
+        i = torch.cuda.current_device()
+        pr = torch.cuda.get_device_properties(i)
+        uuid = getattr(pr, "uuid", None)
+        pci = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0))
+        me = "%s uuid=%s pci=%s" % (getattr(pr, "gcnArchName", pr.name), uuid, pci)
+    if not (dist.is_available() and dist.is_initialized()):
+        return {"world": 1, "backend": None, "devices": [me], "distinct": 1}
+    alls = [None] * dist.get_world_size()
+    dist.all_gather_object(alls, me)
+    return {"world": dist.get_world_size(), "backend": dist.get_backend(), "devices": alls, "distinct": len(set(alls))}
 
 
 def net_tensors(net):

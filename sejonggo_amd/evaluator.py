@@ -48,13 +48,15 @@ def promote_best_model(cleanup=True):
     best_stem = os.path.splitext(conf['BEST_MODEL'])[0]
     for model_name in result.keys():
         if result[model_name] > conf['EVALUATE_MARGIN']:
-            for ext in (".pt", ".h5"):
-                src = os.path.join(conf['MODEL_DIR'], model_name + ext)
-                if os.path.isfile(src):
-                    shutil.copyfile(src, os.path.join(conf['MODEL_DIR'], best_stem + ext))
-                    break
-            else:
+            from .model import _find, drop_sibling
+            src = _find(model_name)
+            if src is None:
                 raise FileNotFoundError("promote_best_model: no file for %r under %r" % (model_name, conf['MODEL_DIR']))
+            dst = os.path.join(conf['MODEL_DIR'], best_stem + os.path.splitext(src)[1])
+            tmp = "%s.tmp%d" % (dst, os.getpid())
+            shutil.copyfile(src, tmp)
+            os.replace(tmp, dst)
+            drop_sibling(dst)          # a best_model.pt left beside a promoted best_model.h5 would keep being loaded
             if cleanup:
                 clean_up_result(result)
             return True

@@ -56,10 +56,18 @@ def _candidates():
 
 
 def _load():
+    """Opens libhdf5 once per process.  Under LOCK, and `_tried` is set LAST: a writer thread that arrives while another one
+    is still inside the search waits for its answer instead of reading a half-made "not available"."""
+    if _tried:
+        return _lib
+    with LOCK:
+        return _load_locked()
+
+
+def _load_locked():
     global _lib, _tried
     if _tried:
         return _lib
-    _tried = True
     for path in _candidates():
         try:
             lib = C.CDLL(path)
@@ -99,6 +107,7 @@ def _load():
         lib._path = path
         _lib = lib
         break
+    _tried = True
     return _lib
 
 

@@ -35,12 +35,21 @@ def _best_stem():
 
 
 def _find(stem):
-    """Path of `<stem>.pt` or `<stem>.h5` under MODEL_DIR (the torch checkpoint wins), or None."""
-    for ext in (".pt", ".h5"):
-        p = os.path.join(_dir(), stem + ext)
-        if os.path.isfile(p):
-            return p
-    return None
+    """Path of `<stem>.pt` or `<stem>.h5` under MODEL_DIR, or None.  When both exist the one written LAST wins (the
+    reference's trainer / evaluator write .h5 files next to our .pt ones: a promoted best_model.h5 must not be shadowed
+    by a stale best_model.pt); on equal timestamps the torch checkpoint."""
+    found = [p for p in (os.path.join(_dir(), stem + ext) for ext in (".pt", ".h5")) if os.path.isfile(p)]
+    if not found:
+        return None
+    return max(found, key=lambda p: (os.stat(p).st_mtime_ns, p.endswith(".pt")))
+
+
+def drop_sibling(path):
+    """A model lives in ONE file: after `path` was (re)written, remove the same stem under the other extension."""
+    stem, ext = os.path.splitext(path)
+    other = stem + (".h5" if ext == ".pt" else ".pt")
+    if os.path.isfile(other):
+        os.remove(other)
 
 
 def _latest_stem():
@@ -114,6 +123,7 @@ def save_model(net, fname):
     torch.save({"state_dict": {k: v.detach().cpu() for k, v in net.state_dict().items()}, "name": net.name,
                 "size": net.size, "n_blocks": len(net.blocks), "channels": net.stem.out_channels}, tmp)
     os.replace(tmp, path)
+    drop_sibling(path)
     return path
 
 

@@ -141,47 +141,3 @@ def back_propagation(result, node):
         parent['mean_value'] = parent['value'] / float(parent['count'])
         parent['virtual_loss'] = 0
         parent = parent['parent'] if parent['parent'] else None
-
-
-def update_root(result, node, action):
-    """nomodel_self_play.py:24-33 (legacy async_simulate callback): graft an evaluated child under the root."""
-    from . import simulation_workers as sw
-    lock = sw.lock
-    if lock is not None:
-        lock.acquire()
-    try:
-        node['subtree'][action] = result
-        node['count'] += 1
-        node['value'] += result['value']
-        node['mean_value'] = node['value'] / float(node['count'])
-        result['virtual_loss'] = 0
-        result['parent'] = node
-    finally:
-        if lock is not None:
-            lock.release()
-
-
-def error_handler(err):
-    print("Error in basic task", err)
-    raise err
-
-
-def async_simulate(node, board, model_indicator, energy, original_player):
-    """nomodel_self_play.py:84-112, the older root-parallel search: `energy` distinct root children (busy-excluded) are each
-    followed down by top_one_action, evaluated and grafted back.  Runs on the in-process pool of simulation_workers
-    (rules and net on the GPU); superseded by async_simulate2 in the reference's own production path."""
-    from . import simulation_workers as sw
-    from .play import top_one_with_virtual_loss
-    if sw.process_pool is None:
-        sw.init_simulation_workers()
-    while energy > 0:
-        action = top_one_with_virtual_loss(node)
-        if action == {}:
-            break                   # every child is busy: the reference spins here until a callback clears a flag
-        child = action['node']
-        child['parent'] = None
-        child['virtual_loss'] += 2
-        a = action['action']
-        sw.process_pool.apply_async(sw.basic_tasks, (child, np.copy(board), a, model_indicator, original_player),
-                                    callback=lambda result, a=a: update_root(result, node, a), error_callback=error_handler)
-        energy -= 1

@@ -363,35 +363,3 @@ def tree_depth(tree):
     if tree['subtree'] is None:
         return 1
     return 1 + max([tree_depth(child) for child in tree['subtree'].values()] or [0])
-
-
-def _color_adjoint(i, j, color, board):
-    """play.py:244-260: paint the empty region that contains the neighbours of (i, j) in `color`, IN PLACE (the recursive
-    helper behind color_board).  The fill is one GPU flood (k_board_query mode 1) seeded with the single point (i, j)."""
-    rb = np.asarray(board)
-    tmp = np.where(rb == color, 2, rb)            # other stones of that colour must not seed the fill
-    tmp[i][j] = color
-    filled = color_board(tmp, color)
-    grown = (filled == color) & (np.asarray(tmp) == 0)
-    for a, b in zip(*np.nonzero(grown)):
-        board[a][b] = color
-    if rb[i][j] == 0 and grown.any():
-        board[i][j] = color          # an empty starting point is painted when the walk steps back onto it from a neighbour
-    return board
-
-
-def show_board_old(board):
-    """play.py:149-158."""
-    for row in get_real_board(board):
-        print(" ".join(u"\u25cb" if c == 1 else u"\u25cf" if c == -1 else u"." for c in row) + " ")
-
-
-def show_tree(x, y, tree, indent=''):
-    """play.py:365-372."""
-    if tree['parent'] is None:
-        print('ROOT p: %s, count: %s' % (tree['p'], tree['count']))
-    elif tree['count'] >= 1:
-        print('%s Move(%s,%s) p: %s, count: %s' % (indent, x, y, tree['p'], tree['count']))
-    for action, node in tree['subtree'].items():
-        ax, ay = index2coord(action)
-        show_tree(ax, ay, node, indent=indent + '--')

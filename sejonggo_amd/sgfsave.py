@@ -72,7 +72,7 @@ def _make_move_dir(root, model_name, pattern, game_no, move_n):
         try:
             os.makedirs(directory)
             return directory, game_no
-        except OSError:
+        except FileExistsError:          # only "somebody owns this number": a full or read-only disk must surface, not spin
             game_no += 1
 
 

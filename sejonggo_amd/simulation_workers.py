@@ -141,30 +141,6 @@ def basic_tasks2(node, board, moves, model_indicator, original_player, process_i
     simulation_result_queue[process_id].put((node, moves))
 
 
-def basic_tasks(node, board, move, model_indicator, original_player):
-    """simulation_workers.py:56-79 (legacy async_simulate task): walk down by top_one_action from the child reached by
-    `move`, evaluate, expand and back the value up to the root of the node's own parent chain."""
-    from .play import index2coord, make_play, top_one_action
-    from .predicting_queue_worker import put_predict_request
-    size = board.shape[-2]
-    moves = [move]
-    while node['subtree'] != {}:
-        pick = top_one_action(node['subtree'])
-        node = pick['node']
-        moves.append(pick['action'])
-    for m in moves:
-        x, y = index2coord(m, size)
-        board, _ = make_play(x, y, board)
-    policy, value = put_predict_request(model_indicator, board)
-    v = _finish_leaf(node, board, policy, value, original_player)
-    while node['parent']:
-        node = node['parent']
-        node['count'] += 1
-        node['value'] += v
-        node['mean_value'] = node['value'] / float(node['count'])
-    return node
-
-
 def board_worker(input_tuple):
     """simulation_workers.py:81-104: the leaf board below one top_n pick; dic['node'] is moved to the leaf."""
     from .play import index2coord, make_play, top_one_action

@@ -14,7 +14,8 @@ def main():
     backend, out_dir = sys.argv[1], sys.argv[2]
     import torch
     import torch.distributed as dist
-    from sejonggo_amd.distributed import init_from_env, tuple_dtype, gather_tuples, shard_games, broadcast_net, net_tensors
+    from sejonggo_amd.distributed import (init_from_env, tuple_dtype, gather_tuples, shard_games, broadcast_net, net_tensors,
+                                          TupleGather, device_identities)
     rank, world, dev = init_from_env(backend)
     dt = tuple_dtype(9)
     n = 3 + 4 * rank          # ragged: rank 0 has 3 tuples, rank 1 has 7
@@ -27,6 +28,27 @@ def main():
     t["state"] = (np.arange(dt["state"].shape[0], dtype=np.uint32) * (rank + 1))[None, :]
     out = gather_tuples(t)
     empty = gather_tuples(t[:0] if rank == world - 1 else t[:1])   # one rank contributes nothing
+    # the pipelined form the self-play loops use: four batches of different lengths (one of them empty on the last rank),
+    # nothing completes before the third submit, batches come back in submit order
+    tg = TupleGather(dt)
+    done_at, got = [], []
+    for k in range(4):
+        m = 0 if (k == 2 and rank == world - 1) else min(n, 1 + k + rank)
+        b = t[:m].copy()
+        b["game_seq"] = k
+        r = tg.submit(b)
+        done_at.append(len(r))
+        got.extend(r)
+    got.extend(tg.flush())
+    pipe_ok = done_at[:2] == [0, 0] and done_at[2:] == [1, 1] and len(got) == 4 and not tg.inflight
+    if rank == 0:
+        for k, a in enumerate(got):
+            want = sum(0 if (k == 2 and r == world - 1) else min(3 + 4 * r, 1 + k + r) for r in range(world))
+            pipe_ok = pipe_ok and a is not None and len(a) == want and bool((a["game_seq"] == k).all()) \
+                and list(a["rank"]) == sorted(a["rank"])
+    else:
+        pipe_ok = pipe_ok and all(a is None for a in got)
+    ident = device_identities()
     # weights: every rank starts from different values; after the broadcast all hold rank 0's
     from sejonggo_amd.net import PolicyValueNet
     torch.manual_seed(100 + rank)
@@ -39,7 +61,8 @@ def main():
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), before=before, after=after, identical=info["identical"],
              checksum=np.int64(info["checksum"]), nbytes=info["bytes"], n_tensors=len(net_tensors(net)),
              out=(np.frombuffer(out.tobytes(), dtype=np.uint8) if out is not None else np.zeros(0, np.uint8)),
-             n_out=(-1 if out is None else len(out)), n_empty=(-1 if empty is None else len(empty)))
+             n_out=(-1 if out is None else len(out)), n_empty=(-1 if empty is None else len(empty)),
+             pipe_ok=bool(pipe_ok), ident_world=ident["world"], ident_n=len(ident["devices"]), ident_distinct=ident["distinct"])
     dist.barrier()
     dist.destroy_process_group()
 

@@ -41,6 +41,10 @@ def _check(res, world):
     assert all(float(x["after"]) == float(res[0]["before"]) for x in res)
     assert all(bool(x["identical"]) for x in res) and len({int(x["checksum"]) for x in res}) == 1
     assert int(r0["n_tensors"]) > 10 and int(r0["nbytes"]) > 0
+    # the pipelined side-stream gather (TupleGather: three stages, two submits of latency, submit order kept) and the
+    # device identities every rank reports for the bench line
+    assert all(bool(x["pipe_ok"]) for x in res)
+    assert all(int(x["ident_world"]) == world and int(x["ident_n"]) == world for x in res)
 
 
 def test_shard_games():

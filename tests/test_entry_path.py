@@ -351,6 +351,42 @@ def test_promote_best_model(tmp_path):
         _restore(conf, old)
 
 
+def test_promoted_keras_file_is_not_shadowed_by_a_stale_checkpoint(tmp_path):
+    """a fresh MODEL_DIR holds best_model.pt (create_initial_model); the reference's trainer then writes
+    model_2.h5 and the evaluator promotes it.  load_best_model / model_name must resolve to the PROMOTED model, and a
+    best_model.h5 dropped next to best_model.pt by the reference's own evaluator (a plain copy) wins by being newer."""
+    import time
+    import torch
+    from sejonggo_amd import evaluator as ev, keras_import as ki, model as M
+    try:
+        ki.h5_module()
+    except ImportError:
+        pytest.skip("no HDF5 reader (h5py / libhdf5) on this box")
+    conf, old = _with_conf(tmp_path, SIZE=5, N_RESIDUAL_BLOCKS=1, NET_CHANNELS=8, EVALUATE_MARGIN=.55)
+    try:
+        os.makedirs(conf['MODEL_DIR']); os.makedirs(conf['EVAL_DIR'])
+        assert M.load_best_model().name == "model_1"                               # writes model_1.pt + best_model.pt
+        assert os.path.isfile(os.path.join(conf['MODEL_DIR'], "best_model.pt"))
+        torch.manual_seed(5)
+        cand = M.PolicyValueNet(5, 1, 8, name="model_2").eval()
+        ki.save_keras_h5(os.path.join(conf['MODEL_DIR'], "model_2.h5"), cand)      # a .h5-only candidate
+        for g in range(10):
+            ev.save_eval_game("model_2", g, "model_2")
+        assert ev.promote_best_model() is True
+        assert sorted(f for f in os.listdir(conf['MODEL_DIR']) if f.startswith("best_model")) == ["best_model.h5"]
+        assert M.model_name("BEST") == "model_2"
+        best = M.load_best_model()
+        assert best.name == "model_2" and torch.allclose(best.p_fc.weight, cand.p_fc.weight)
+        # both extensions present (the reference's evaluator copied a .h5 beside our .pt): the newer file wins
+        M.save_model(M.PolicyValueNet(5, 1, 8, name="model_1"), "best_model")       # -> best_model.pt, drops the .h5
+        assert M.model_name("BEST") == "model_1"
+        time.sleep(0.02)
+        ki.save_keras_h5(os.path.join(conf['MODEL_DIR'], "best_model.h5"), cand)
+        assert M.model_name("BEST") == "model_2" and M.load_best_model().name == "model_2"
+    finally:
+        _restore(conf, old)
+
+
 @pytest.mark.gpu
 def test_evaluation_worker_on_the_device(tmp_path):
     """evaluate_worker.NoModelEvaluateWorker's body: best vs latest as concurrent two-model slots of the device engine, eval

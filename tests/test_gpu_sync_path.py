@@ -272,49 +272,6 @@ def test_gtp_session_matches_reference(sync_env):
         pq.destroy_predicting_workers([0])
 
 
-def test_legacy_helpers_on_the_gpu(sync_env):
-    """play._color_adjoint (play.py:244-260) against a plain restatement; nomodel_self_play.async_simulate (the older
-    root-parallel search, :84-112) runs on the in-process pool and grafts `energy` evaluated children under the root."""
-    from sejonggo_amd import nomodel_self_play as ns, play, predicting_queue_worker as pq, simulation_workers as sw
-    from sejonggo_amd.stub_nets import make_stub
-    rng = np.random.RandomState(4)
-    for _ in range(6):
-        b = rng.choice([-1, 0, 0, 0, 1], size=(9, 9))
-        i, j = [int(v) for v in rng.randint(0, 9, size=2)]
-        color = int(rng.choice([-1, 1]))
-        want = b.copy()
-
-        def fill(a, c):                                   # the reference's recursion, iteratively
-            stack = [(a, c)]
-            while stack:
-                u, v = stack.pop()
-                for du, dv in ((-1, 0), (1, 0), (0, -1), (0, 1)):
-                    x, y = u + du, v + dv
-                    if 0 <= x < 9 and 0 <= y < 9 and want[x][y] == 0:
-                        want[x][y] = color
-                        stack.append((x, y))
-        fill(i, j)
-        got = b.copy()
-        assert play._color_adjoint(i, j, color, got) is got and np.array_equal(got, want)
-    S = 9
-    sync_env.update({'SIZE': S, 'MCTS_SIMULATIONS': 16, 'ENERGY': 4, 'GPUs': [0]})
-    net = make_stub("hash", S)
-    pq.set_model_factory(lambda kind: net)
-    pq.init_predicting_workers([0])
-    try:
-        board, _ = play.game_init(S)
-        pol, _ = net.predict_on_batch(board)
-        tree = play.new_tree(pol[0], board, add_noise=False)
-        sw.init_simulation_workers()
-        ns.async_simulate(tree, board, "BEST", 4, 1)
-        assert tree['count'] == 4 and sum(1 for c in tree['subtree'].values() if c['count'] == 1 and c['subtree']) == 4
-        assert all(c['virtual_loss'] == 0 for c in tree['subtree'].values())
-    finally:
-        sw.destroy_simulation_workers()
-        pq.set_model_factory(None)
-        pq.destroy_predicting_workers([0])
-
-
 @pytest.mark.parametrize("seed", [201, 202, 203, 204, 205, 206])
 def test_fuzzed_two_model_games_device_equals_host(sync_env, seed, monkeypatch):
     """Two-model games inside k_search against the host dict-tree game loop (itself pinned by the reference's two-model
