@@ -199,10 +199,12 @@ typedef struct sgo_game_result {
     int32_t last_player; /* 'player' when the loop ended (used for "X+R") */
     int32_t done;
     int32_t first_model; /* two_model games: which model moved first = plays black (0 = model1, 1 = model2) */
+    int32_t blocks_high_water; /* most tree blocks of its pool the game ever held at once (of sgo_blocks_per_game) */
 } sgo_game_result;
 
 sgo_ctx *sgo_ctx_create(const sgo_config *cfg);
 void sgo_ctx_destroy(sgo_ctx *ctx);
+int sgo_blocks_per_game(sgo_ctx *ctx);   /* the per-game tree-block pool this context was created with */
 /* (Re)start game slots.  noise: [n][A] float64 Dirichlet draws (np.random.dirichlet stand-in, consumed
  * when a tree is created); uniforms: [n][n_uniforms] float64 in [0,1) consumed one per sampled move
  * (np.random.choice stand-in); resign: [n] thresholds, NaN or 0 = None.  HOST pointers; they are copied before the call

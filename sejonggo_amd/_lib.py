@@ -21,7 +21,7 @@ SYMBOLS = [
     "sgo_last_error", "sgo_version", "sgo_device_count", "sgo_set_device", "sgo_plane_words", "sgo_packed_words",
     "sgo_apad", "sgo_game_init", "sgo_make_play", "sgo_take_stones", "sgo_board_query", "sgo_legal_moves", "sgo_get_winner", "sgo_sym_apply",
     "sgo_sym_invert_policy", "sgo_sym_lut", "sgo_pack_dev", "sgo_unpack_dev", "sgo_advance_legal_dev",
-    "sgo_legal_dev", "sgo_score_dev", "sgo_nn_pack_dev", "sgo_bias_act_dev", "sgo_conv3x3_bias_act_dev", "sgo_conv3x3_tower_dev", "sgo_conv3x3_stem_dev", "sgo_conv_tile_order", "sgo_conv_tower_kernel", "sgo_conv_tower_slice_cap", "sgo_advance_mode", "sgo_debug_counters", "sgo_ctx_create", "sgo_ctx_destroy", "sgo_start_games", "sgo_start_games2", "sgo_eval_models",
+    "sgo_legal_dev", "sgo_score_dev", "sgo_nn_pack_dev", "sgo_bias_act_dev", "sgo_conv3x3_bias_act_dev", "sgo_conv3x3_tower_dev", "sgo_conv3x3_stem_dev", "sgo_conv_tile_order", "sgo_conv_tower_kernel", "sgo_conv_tower_slice_cap", "sgo_advance_mode", "sgo_debug_counters", "sgo_ctx_create", "sgo_ctx_destroy", "sgo_blocks_per_game", "sgo_start_games", "sgo_start_games2", "sgo_eval_models",
     "sgo_step", "sgo_step_fused", "sgo_collect", "sgo_drain_records", "sgo_game_results", "sgo_root_table", "sgo_tree_serialize", "sgo_tree_dump",
     "sgo_game_board", "sgo_set_halt", "sgo_advance_timing",
 ]
@@ -51,13 +51,15 @@ class MoveRecord(C.Structure):
 
 class GameResult(C.Structure):
     _fields_ = [("winner", C.c_int32), ("black", C.c_int32), ("white", C.c_double), ("end_reason", C.c_int32),
-                ("n_moves", C.c_int32), ("last_player", C.c_int32), ("done", C.c_int32), ("first_model", C.c_int32)]
+                ("n_moves", C.c_int32), ("last_player", C.c_int32), ("done", C.c_int32), ("first_model", C.c_int32),
+                ("blocks_high_water", C.c_int32)]
 
 
 MOVE_RECORD_DTYPE = np.dtype([("game", "<i4"), ("game_seq", "<i4"), ("move_n", "<i4"), ("action", "<i4"),
                               ("player", "<i4"), ("value", "<f4")])
 GAME_RESULT_DTYPE = np.dtype([("winner", "<i4"), ("black", "<i4"), ("white", "<f8"), ("end_reason", "<i4"),
-                              ("n_moves", "<i4"), ("last_player", "<i4"), ("done", "<i4"), ("first_model", "<i4")], align=True)
+                              ("n_moves", "<i4"), ("last_player", "<i4"), ("done", "<i4"), ("first_model", "<i4"),
+                              ("blocks_high_water", "<i4")], align=True)
 
 _lib = None
 gpu_touched_pid = None   # pid of the process in which this module first made a HIP call (fork-safety checks)

@@ -57,6 +57,7 @@ struct GameState {
     float other_value, other_mean;
     float resign2;
     int32_t has_resign2;
+    int32_t min_free, pad_;               // fewest free blocks the pool ever held during this game (high-water mark = cap - min_free)
 };
 
 struct Counters {
@@ -642,6 +643,7 @@ __global__ __launch_bounds__(64) void k_search(Ctx c, const float *policy, const
                     if (st.free_top <= 0) { fail(SGO_ERR_CAPACITY); break; }
                     onr = c.freeList[(size_t)g * c.cap + st.free_top - 1];
                     st.free_top--;
+                    if (st.free_top < st.min_free) st.min_free = st.free_top;
                     for (int i = lane; i < G::RW; i += 64) c.pos[(e.gb0 + onr) * G::RW + i] = c.pos[(e.gb0 + nr) * G::RW + i];
                     for (int i = lane; i < G::NW; i += 64) c.legal[(e.gb0 + onr) * G::NW + i] = c.legal[(e.gb0 + nr) * G::NW + i];
                     if (lane == 0) { c.bParent[e.gb0 + onr] = -1; c.bSlot[e.gb0 + onr] = -2; }
@@ -694,6 +696,7 @@ __global__ __launch_bounds__(64) void k_search(Ctx c, const float *policy, const
             if (st.free_top <= 0) { fail(SGO_ERR_CAPACITY); break; }
             const int nb = c.freeList[(size_t)g * c.cap + st.free_top - 1];
             st.free_top--;
+            if (st.free_top < st.min_free) st.min_free = st.free_top;
             const size_t fo = fbase + (st.fifo_tail % (2 * MAXE));
             if (lane == 0) {
                 c.bParent[e.gb0 + nb] = pb;
@@ -850,6 +853,7 @@ __global__ __launch_bounds__(64) void k_start(Ctx c, int n, StageLayout L, int h
     }
     for (int b = lane; b < c.cap - 1; b += 64) c.freeList[(size_t)g * c.cap + b] = c.cap - 1 - b;  // pops give 1,2,3,...
     st.free_top = c.cap - 1;
+    st.min_free = c.cap - 1;
     if (lane == 0) {
         c.bParent[gb0] = -1;
         c.bSlot[gb0] = -2;  // no children yet
@@ -1002,6 +1006,11 @@ sgo_ctx *sgo_ctx_create(const sgo_config *cfg) {
         ctx_free(c); delete x; return nullptr;
     }
     return x;
+}
+
+int sgo_blocks_per_game(sgo_ctx *x) {
+    if (!x) { set_error("sgo_blocks_per_game: bad argument"); return SGO_ERR_ARG; }
+    return x->c.cap;
 }
 
 void sgo_ctx_destroy(sgo_ctx *x) {
@@ -1194,6 +1203,7 @@ int sgo_game_results(sgo_ctx *x, int n, const int32_t *slots, sgo_game_result *o
         out[i].winner = s.winner; out[i].black = s.black; out[i].white = s.white; out[i].end_reason = s.end_reason;
         out[i].n_moves = s.n_moves; out[i].last_player = s.last_player; out[i].done = (s.phase == PH_DONE) ? 1 : 0;
         out[i].first_model = s.first_model;
+        out[i].blocks_high_water = c.cap - s.min_free;
         if (s.error) out[i].done = s.error;
     }
     return SGO_OK;

@@ -333,6 +333,7 @@ class SelfPlayEngine(object):
             'end_reason': END_REASONS[int(result["end_reason"])],
             'black_points': int(result["black"]), 'white_points': float(result["white"]),
             'slot': int(slot), 'id': self.game_ids.get(int(slot)),
+            'blocks_high_water': int(result["blocks_high_water"]),
         }
 
     def _eval_game_data(self, slot, result):

@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--policy-gain", type=float, default=1.0,
                     help="multiply the policy head's last layer: > 1 makes a random-init net's priors peaky, like a trained net's "
                          "(concentrated search -> the kept subtree holds most of the tree -> the block pool is stressed)")
+    ap.add_argument("--json", default="", help="write the summary as JSON to this path")
+    ap.add_argument("--energy", type=int, default=8)
     ap.add_argument("--no-resign", type=int, default=0, help="1: RESIGNATION_PERCENT = 1 (every game runs to its natural end)")
     a = ap.parse_args()
     import numpy as np
@@ -31,7 +33,7 @@ def main():
     from sejonggo_amd.net import build_fused_net
     from sejonggo_amd.selfplay_worker import run_selfplay
     d = tempfile.mkdtemp(prefix="sgo_stress_")
-    conf.update({'SIZE': a.size, 'MCTS_SIMULATIONS': a.sims, 'ENERGY': 8, 'STOP_EXPLORATION': a.stop, 'SELF_PLAY_DIR': d,
+    conf.update({'SIZE': a.size, 'MCTS_SIMULATIONS': a.sims, 'ENERGY': a.energy, 'STOP_EXPLORATION': a.stop, 'SELF_PLAY_DIR': d,
                  'GAMES_PER_GPU': a.resident})
     if a.no_resign:
         conf['RESIGNATION_PERCENT'] = 1.0
@@ -53,12 +55,14 @@ def main():
         fnet, _ = build_fused_net(a.size, a.blocks, a.channels, name="stress")
     pq.set_model_factory(lambda kind: fnet)
     lens, results = [], []
+    probe = {}
     t0 = time.time()
     stats = {}
     last = [t0]
 
     def on_game(g, gd):
         lens.append(len(gd['moves']))
+        probe.setdefault("hw", []).append(gd.get('blocks_high_water', 0))
         results.append(gd['result'] + " " + gd['end_reason'])
         if time.time() - last[0] > 30:          # a progress line at least every 30 s (gpurun takes a silent run for hung)
             last[0] = time.time()
@@ -75,12 +79,13 @@ def main():
     import ctypes as C
     from sejonggo_amd import engine as eng_mod
     real_engine = eng_mod.SelfPlayEngine
-    probe = {}
 
     class Probed(real_engine):
         def __init__(self, *aa, **kk):
             real_engine.__init__(self, *aa, **kk)
             probe["eng"] = self
+            probe["cap"] = int(self.lib.sgo_blocks_per_game(self.ctx))
+            probe.setdefault("hw", [])
 
         def step(self):
             st = real_engine.step(self)
@@ -115,6 +120,20 @@ def main():
     lens = np.array(lens)
     print("played %d games in %.1f s: %d positions, %.1f positions/s; length min/mean/max %d/%.1f/%d" % (
         played, dt, lens.sum(), lens.sum() / dt, lens.min(), lens.mean(), lens.max()))
+    allhw = np.array(probe.get("hw", [0]) or [0])
+    print("tree-block pool per game: %d blocks; high-water mark of finished games: max %d (%.0f %% of the pool), p99 %d, median %d" % (
+        probe.get("cap", -1), allhw.max(), 100.0 * allhw.max() / max(probe.get("cap", 1), 1), int(np.percentile(allhw, 99)),
+        int(np.median(allhw))))
+    if a.json:
+        import json
+        json.dump({"config": vars(a), "games_played": int(played), "games_started": a.games, "discarded": int(max(0, a.games - played)),
+                   "seconds": dt, "positions": int(lens.sum()), "positions_per_sec": float(lens.sum() / dt),
+                   "game_length": {"min": int(lens.min()), "mean": float(lens.mean()), "max": int(lens.max())},
+                   "blocks_per_game": probe.get("cap"), "pool_high_water": {"max": int(allhw.max()), "p99": int(np.percentile(allhw, 99)),
+                                                                           "median": int(np.median(allhw))},
+                   "host_seconds": {k: stats.get(k) for k in ("step", "turnover", "writer_wait")}, "engine_steps": stats.get("steps"),
+                   "end_reasons": {k: sum(1 for r in results if r.endswith(k)) for k in ("BOTH_PASSED", "PLAYED ALL MOVES", "resign")}},
+                  open(a.json, "w"), indent=1)
     print("end reasons:", {k: sum(1 for r in results if r.endswith(k)) for k in ("BOTH_PASSED", "PLAYED ALL MOVES", "resign")})
     print("sample results:", results[:6])
 
