@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--policy-gain", type=float, default=1.0,
                     help="multiply the policy head's last layer: > 1 makes a random-init net's priors peaky, like a trained net's "
                          "(concentrated search -> the kept subtree holds most of the tree -> the block pool is stressed)")
+    ap.add_argument("--max-plies", type=int, default=0, help="cap on a game's length (0 = the rules' 2 * S * S)")
     ap.add_argument("--json", default="", help="write the summary as JSON to this path")
     ap.add_argument("--energy", type=int, default=8)
     ap.add_argument("--no-resign", type=int, default=0, help="1: RESIGNATION_PERCENT = 1 (every game runs to its natural end)")
@@ -110,7 +111,7 @@ def main():
     hb = threading.Thread(target=heartbeat, daemon=True)
     hb.start()
     played = run_selfplay(0, "BEST_SYM", n_games=a.games, games_per_gpu=a.resident, on_game=on_game, stats=stats,
-                          engine_kwargs={'blocks_per_game': a.blocks_per_game})
+                          engine_kwargs=dict({'blocks_per_game': a.blocks_per_game}, **({'num_moves': a.max_plies} if a.max_plies else {})))
     stop.set()
     dt = time.time() - t0
     print("host seconds: stepping %.1f, turnover %.1f, waiting for writers at the end %.1f" % (
