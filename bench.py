@@ -418,9 +418,9 @@ def run_rank(args):
         positions = world * G * args.steps
         per_launch = adv_pos / max(adv_n, 1)
         avg_ms = adv_ms / max(adv_n, 1)
-        # fused launch = board_advance + the child's fp16 NHWC-32 network-input row (S*S*32*2 B) written by the same kernel
-        nn_row = S * S * 32 * 2 if eng.fused_pack else 0
-        per_leaf = ALGO_BYTES.get(S, 0) + nn_row
+        # record read + record written + legal set.  No network-input row exists any more: the stem kernel reads
+        # the 768-byte records board_advance wrote (sgo_stem_packed_dev), so nothing else leaves this kernel
+        per_leaf = ALGO_BYTES.get(S, 0)
         algo = per_leaf * per_launch
         achieved = algo / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         flops = net.flops_per_eval() if hasattr(net, "flops_per_eval") else 0
@@ -441,14 +441,11 @@ def run_rank(args):
                        "backend": args.backend, "weights_broadcast": bcast},
             "rccl": dict(rccl, tuples_on_rank0=gathered[0],
                          gather="TupleGather: counts all_gather + padded gather to rank 0, 3-stage pipeline on a side stream"),
-            "roofline_board_advance": {"bound": "hbm", "kernel": ("board_advance fused with nn_input_pack in situ (k_board_advance_rows_nn: make_play + legal set + history move + "
-                                                                  "the child's fp16 NHWC-32 network-input row, one half-wavefront per leaf)" if eng.fused_pack else
-                                                                  "board_advance in situ (make_play + legal set + history move of the step's leaf list; k_board_advance_rows up to 32 768 leaves, k_board_advance above)"),
+            "roofline_board_advance": {"bound": "hbm", "kernel": "board_advance in situ (make_play + legal set + history move of the step's leaf list; "
+                                                                 "k_board_advance_rows, one half-wavefront per leaf, up to 32 768 leaves, k_board_advance above)",
                          "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": None, "algorithmic_bytes_per_position": per_leaf,
-                         "accounting": {"board_advance": ALGO_BYTES.get(S, 0), "nn_input_row_fused": nn_row,
-                                        "unfused_for_comparison": "board_advance %d B + a separate pack kernel that re-reads the record and writes 17 fp16 planes: %d B"
-                                                                  % (ALGO_BYTES.get(S, 0), ALGO_BYTES.get(S, 0) + 17 * S * S * 2)},
+                         "network_input": "none: the stem reads the packed records (%s)" % ("sgo_stem_packed_dev" if getattr(eng, "packed", False) else "tensor route: k_nn_pack"),
                          "positions_per_launch": per_launch, "avg_launch_ms": avg_ms, "launches": adv_n},
             "net": {"evals": int(evals), "flops_per_eval": flops,
                     "achieved_tflops": (evals * sym_mult * flops / dt / 1e12) if flops else None,
@@ -483,7 +480,7 @@ def run_rank(args):
                     pass
         else:
             out["roofline"] = dict(out["roofline_board_advance"])
-        tr = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json" if eng.fused_pack else "r01_pmc_traffic.json")
+        tr = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
         if os.path.isfile(tr) and (S, G, E) == (19, 1024, 8):
             try:
                 out["roofline_board_advance"]["traffic"] = json.load(open(tr)).get("traffic_bytes_per_launch_corrected")

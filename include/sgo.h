@@ -131,8 +131,18 @@ int sgo_conv3x3_bias_act_dev(int n, int h, int w, int c, int k, int pad, const v
 int sgo_conv3x3_tower_dev(int n, int h, int w, const void *d_x, const void *d_w, const void *d_bias, const void *d_skip,
                           void *d_y, void *stream);
 /* The hand-written CDNA4 kernel for the stem (c = 32: the 17 input planes zero-padded, k = 256, pad 0, no skip;
- * csrc/sgo_stem.hpp; model.py:57-60).  x [n][h][w][32] is the network-input row format of sgo_step_fused / layout 2. */
+ * csrc/sgo_stem.hpp; model.py:57-60).  x [n][h][w][32] is layout 2 of sgo_nn_pack_dev: the route of callers that hold board
+ * TENSORS (put_predict_request); the self-play engine feeds the net through sgo_stem_packed_dev below instead. */
 int sgo_conv3x3_stem_dev(int n, int h, int w, const void *d_x, const void *d_w, const void *d_bias, void *d_y, void *stream);
+/* The stem straight from PACKED POSITION RECORDS (csrc/sgo_stem_packed.hpp; model.py:57-60 + symmetry.py:127-132): row i of the
+ * output is relu(conv3x3_valid(planes of sym_k(record d_index[i])) + bias), y [n][S-2][S-2][256] fp16.  The 16 stone planes are
+ * expanded from the record's bit-planes in LDS (relative to the side to move, symmetry on the gather side); the colour plane
+ * (+-1 over the whole board, 'valid' convolution) is the per-position constant c * d_wcol[k] added to the bias.
+ * d_w10: [256][10][16] fp16 -- taps 0..8 (dy * 3 + dx) of the 16 stone planes, tap 9 zero; d_bias fp16 [256];
+ * d_wcol float [256] = sum over the 9 taps of the colour plane's weights.  d_index NULL = records 0..n-1; d_sym_k (device
+ * int, optional) overrides sym_k when the kernel runs.  No network-input tensor exists on this route. */
+int sgo_stem_packed_dev(int S, int n, const uint32_t *d_records, const int32_t *d_index, int sym_k, const int32_t *d_sym_k,
+                        const void *d_w10, const void *d_bias, const float *d_wcol, void *d_y, void *stream);
 /* Which hand-written kernel sgo_conv3x3_tower_dev launches: 1 = k_conv4w (csrc/sgo_conv4w.hpp: two 256-thread workgroups per
  * CU, 256 pixels x 128 channels each; the default), 0 = k_conv8w (csrc/sgo_conv8w.hpp: one 512-thread workgroup per CU,
  * 256 pixels x 256 channels).  Same results bit for bit.  Returns the previous choice; other values only query. */
@@ -226,14 +236,20 @@ int sgo_eval_models(sgo_ctx *ctx, int cap, int32_t *models);
  * search is complete, computes the new leaf positions, and reports what must be evaluated next.
  * Synchronises `stream` once to return `st`. */
 int sgo_step(sgo_ctx *ctx, const float *d_policy, const float *d_value, int sym_k, void *stream, sgo_status *st);
-/* sgo_step with nn_input_pack FUSED into board_advance (predicting_queue_worker.py:53-71's batch assembly): the kernel
- * that plays a leaf's move also writes that leaf's network-input row -- fp16, NHWC with the channels zero-padded to 32
- * ([n_eval][S][S][32], layout 2 of sgo_nn_pack_dev), transformed by symmetry next_k -- into d_nn_in, and the (at most one
- * per game) root requests are packed by a small kernel behind it.  No sgo_collect call is needed afterwards; pass next_k
- * as sym_k of the following step.  Falls back to separate kernels inside when the leaf list exceeds the fused form's
- * launch shape (> 32 768 leaves). */
-int sgo_step_fused(sgo_ctx *ctx, const float *d_policy, const float *d_value, int sym_k, int next_k, void *d_nn_in,
-                   void *stream, sgo_status *st);
+/* The same step in two halves, for launch chains that must not wait for the host (hipGraph capture, two half-populations
+ * alternating on two streams): sgo_step_enqueue queues k_search / k_compact / board_advance and the copy of the status words to
+ * pinned host memory on `stream` and returns at once; the symmetry the consumed evaluations were produced under is read from
+ * DEVICE memory (*d_sym_k, 0..7) when the kernel runs, so one captured chain serves every symmetry.  d_policy / d_value must
+ * stay valid until the chain has run (rows beyond the listed count are ignored).  After the caller has synchronised the stream
+ * (or an event behind the enqueue), sgo_step_status returns what that step reported.  No board_advance timing in this form. */
+int sgo_step_enqueue(sgo_ctx *ctx, const float *d_policy, const float *d_value, const int32_t *d_sym_k, void *stream);
+int sgo_step_status(sgo_ctx *ctx, sgo_status *st);
+/* Where the evaluation list of the last step lives ON THE DEVICE, for consumers that read packed records directly
+ * (sgo_stem_packed_dev): *d_records = the context's record array (sgo_packed_words(S) words per record), *d_index = the
+ * record index of every row of the list (n_eval of them valid, in the order results are expected), *d_models = which model
+ * evaluates each row (two_model contexts).  The pointers stay valid for the life of the context; the contents change with
+ * every step.  Returns the capacity of the list (n_games * energy). */
+int sgo_eval_list(sgo_ctx *ctx, const uint32_t **d_records, const int32_t **d_index, const int32_t **d_models);
 /* Network input for the positions listed by the last sgo_step (same order as the results expected). */
 int sgo_collect(sgo_ctx *ctx, int sym_k, int layout, int dtype, void *d_nn_in, void *stream);
 /* Move records produced so far (HOST buffers): recs[cap], boards packed [cap][packed_words],

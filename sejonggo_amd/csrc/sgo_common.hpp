@@ -42,14 +42,6 @@ int launch_advance_legal(int S, int n, const uint32_t *d_in, const int32_t *d_in
 int launch_advance_split(int S, int n_max, const int *d_n, const uint32_t *d_in, const int32_t *d_in_idx,
                          const int32_t *d_moves, const int32_t *d_colors, uint32_t *d_out, const int32_t *d_out_idx,
                          uint32_t *d_legal, const int32_t *d_legal_idx, int32_t *d_status, hipStream_t st);
-// board_advance fused with nn_input_pack (fp16 NHWC-32 rows d_nn_row[i] of d_nn_out, symmetry k); only up to
-// advance_rows_nn_fits() leaves (the half-wave-per-leaf form)
-bool advance_rows_nn_fits(int n_max);
-int launch_advance_rows_nn(int S, int n_max, const int *d_n, const uint32_t *d_in, const int32_t *d_in_idx, const int32_t *d_moves,
-                           uint32_t *d_out, const int32_t *d_out_idx, uint32_t *d_legal, const int32_t *d_legal_idx,
-                           const int32_t *d_nn_row, int k, void *d_nn_out, hipStream_t st);
-int launch_nn_pack_rows(int S, int n_max, const int *d_n, const uint32_t *d_packed, const int32_t *d_idx, const int32_t *d_rows, int k,
-                        void *d_out, hipStream_t st);
 int launch_nn_pack(int S, int n, const uint32_t *d_packed, const int32_t *d_idx, int k, int layout, int dtype,
                    void *d_out, hipStream_t st);
 int launch_score(int S, int n, const uint32_t *d_packed, const int32_t *d_idx, double komi, int32_t *d_result,

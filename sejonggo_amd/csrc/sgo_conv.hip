@@ -11,6 +11,7 @@
 #include "sgo_conv8w.hpp"
 #include "sgo_conv4w.hpp"
 #include "sgo_stem.hpp"
+#include "sgo_stem_packed.hpp"
 
 namespace {
 int g_tower_kernel = 1;       // 1: k_conv4w (two 256-thread workgroups per CU; default, +2-3 %), 0: k_conv8w (one 512-thread workgroup per CU)
@@ -95,6 +96,24 @@ extern "C" int sgo_conv3x3_stem_dev(int n, int h, int w, const void *d_x, const 
             return SGO_ERR_ARG;
         }
     }
+    SGO_HIP(hipGetLastError());
+    return SGO_OK;
+}
+
+extern "C" int sgo_stem_packed_dev(int S, int n, const uint32_t *d_records, const int32_t *d_index, int sym_k, const int32_t *d_sym_k,
+                                   const void *d_w10, const void *d_bias, const float *d_wcol, void *d_y, void *stream) {
+    using namespace sgo;
+    if (n <= 0 || !d_records || !d_w10 || !d_bias || !d_wcol || !d_y || sym_k < 0 || sym_k > 7) {
+        set_error("sgo_stem_packed_dev: bad argument");
+        return SGO_ERR_ARG;
+    }
+    if ((((uintptr_t)d_w10 | (uintptr_t)d_y | (uintptr_t)d_bias) & 15) || ((uintptr_t)d_records & 3) || ((uintptr_t)d_wcol & 3)) {
+        set_error("sgo_stem_packed_dev: w10, bias, y must be 16-byte aligned");
+        return SGO_ERR_ARG;
+    }
+    int rc = 0;
+    SGO_DISPATCH(S, rc = sgo_stemp::launch<kS>(n, d_records, d_index, sym_k, d_sym_k, d_w10, d_bias, d_wcol, d_y, (hipStream_t)stream));
+    if (rc != 0) { set_error("sgo_stem_packed_dev: launch rejected (batch too large for 32-bit pixel indices)"); return SGO_ERR_ARG; }
     SGO_HIP(hipGetLastError());
     return SGO_OK;
 }

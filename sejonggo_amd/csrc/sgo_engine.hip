@@ -136,6 +136,7 @@ struct HostSide {  // not passed to kernels
     hipEvent_t ev_stage = nullptr;             // k_start has consumed the staged batch (host block and device twin)
     bool stage_busy = false;
     hipStream_t last_stream = nullptr;         // stream of the last sgo_step (records are drained behind it)
+    bool lds_attr_set = false;                 // k_search's > 64 KiB dynamic-LDS attribute has been set
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // bracket board_advance inside sgo_step
     double adv_ms = 0;
     long long adv_launches = 0, adv_positions = 0;
@@ -375,7 +376,7 @@ struct Eng {
 
 // ---------------------------------------------------------------------------------------- k_search
 template <int S>
-__global__ __launch_bounds__(64) void k_search(Ctx c, const float *policy, const float *value, int sym_k) {
+__global__ __launch_bounds__(64) void k_search(Ctx c, const float *policy, const float *value, int sym_k_imm, const int32_t *sym_k_dev) {
     using G = Geo<S>;
     extern __shared__ int32_t lds[];
     int32_t *queue = lds;                       // [cap]
@@ -386,6 +387,7 @@ __global__ __launch_bounds__(64) void k_search(Ctx c, const float *policy, const
     const int lane = threadIdx.x;
     Eng<S> e(c, g);
     GameState st = c.gs[g];
+    const int sym_k = sym_k_dev ? (*sym_k_dev & 7) : sym_k_imm;   // device-side value: one captured launch chain serves every symmetry
     const int32_t *lut = c.symLut + (size_t)sym_k * G::A;
     const size_t fbase = (size_t)g * (2 * MAXE);
     const size_t rbase = (size_t)g * c.E;
@@ -1084,71 +1086,82 @@ static int start_games_impl(sgo_ctx *x, int n, const int32_t *slots, const doubl
     return SGO_OK;
 }
 
-static int step_impl(sgo_ctx *x, const float *d_policy, const float *d_value, int sym_k, int next_k, void *d_nn_in, void *stream,
-                     sgo_status *out);
-
-int sgo_step(sgo_ctx *x, const float *d_policy, const float *d_value, int sym_k, void *stream, sgo_status *out) {
-    return step_impl(x, d_policy, d_value, sym_k, 0, nullptr, stream, out);
-}
-
-int sgo_step_fused(sgo_ctx *x, const float *d_policy, const float *d_value, int sym_k, int next_k, void *d_nn_in, void *stream,
-                   sgo_status *out) {
-    if (!d_nn_in || next_k < 0 || next_k > 7) { set_error("sgo_step_fused: bad argument"); return SGO_ERR_ARG; }
-    return step_impl(x, d_policy, d_value, sym_k, next_k, d_nn_in, stream, out);
-}
-
-static int step_impl(sgo_ctx *x, const float *d_policy, const float *d_value, int sym_k, int next_k, void *d_nn_in, void *stream,
-                     sgo_status *out) {
-    if (!x || !out || sym_k < 0 || sym_k > 7) { set_error("sgo_step: bad argument"); return SGO_ERR_ARG; }
+// Everything a step runs on the GPU, queued on `st` without waiting: k_search (consumes the evaluations of the list the previous
+// step produced, selects / moves), k_compact (dense evaluation list + leaf list + status words), board_advance for the new
+// leaves, and the copy of the status words to pinned host memory.  No host synchronisation, no host-side shape dependence: the
+// chain can be captured in a hipGraph and replayed (timing = false then: event timestamps do not exist inside a graph).
+static int step_enqueue(sgo_ctx *x, const float *d_policy, const float *d_value, int sym_k, const int32_t *d_sym_k, hipStream_t st,
+                        bool timing) {
     Ctx &c = x->c;
-    hipStream_t st = (hipStream_t)stream;
     x->h.last_stream = st;
-    if (c.last_n_eval > 0 && (!d_policy || !d_value)) {
-        set_error("sgo_step: the previous step listed positions to evaluate; policy/value are required");
-        return SGO_ERR_STATE;
-    }
     SGO_DISPATCH(c.S, {
         const size_t lds = search_lds<kS>(c);
-        if (lds > 64 * 1024)
+        if (lds > 64 * 1024 && !x->h.lds_attr_set) {
             SGO_HIP(hipFuncSetAttribute((const void *)k_search<kS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        k_search<kS><<<dim3(c.G), dim3(64), lds, st>>>(c, d_policy, d_value, sym_k);
+            x->h.lds_attr_set = true;
+        }
+        k_search<kS><<<dim3(c.G), dim3(64), lds, st>>>(c, d_policy, d_value, sym_k, d_sym_k);
     });
     SGO_HIP(hipGetLastError());
     k_compact<<<dim3(1), dim3(1024), 0, st>>>(c);
     SGO_HIP(hipGetLastError());
-    // board_advance for the new leaves, bracketed by HIP events on this stream
-    SGO_HIP(hipEventRecord(x->h.ev0, st));
-    const int max_leaf = c.G * c.E;
-    // parents (leafIn) and freshly allocated blocks (leafOut) are disjoint block sets => split form
-    const bool fused = d_nn_in && advance_rows_nn_fits(max_leaf);
-    if (fused) {
-        // one kernel: parent record -> child record + legal bits + the child's fp16 NHWC-32 network-input row
-        CK(launch_advance_rows_nn(c.S, max_leaf, &c.dstatus->n_leaf, c.pos, c.leafIn, c.leafMv, c.pos, c.leafOut, c.legal,
-                                  c.leafOut, c.leafRow, next_k, d_nn_in, st));
-    } else {
-        CK(launch_advance_split(c.S, max_leaf, &c.dstatus->n_leaf, c.pos, c.leafIn, c.leafMv, nullptr, c.pos, c.leafOut, c.legal,
-                                c.leafOut, nullptr, st));
-    }
-    SGO_HIP(hipEventRecord(x->h.ev1, st));
-    if (d_nn_in) {
-        // root requests (at most one per game) keep the stand-alone pack; without the fused form so do the leaves
-        CK(launch_nn_pack_rows(c.S, c.G, &c.dstatus->n_root, c.pos, c.rootIdx, c.rootRow, next_k, d_nn_in, st));
-        if (!fused) CK(launch_nn_pack_rows(c.S, max_leaf, &c.dstatus->n_leaf, c.pos, c.leafOut, c.leafRow, next_k, d_nn_in, st));
-    }
+    // board_advance for the new leaves (parents = leafIn and freshly allocated blocks = leafOut are disjoint block sets => the
+    // split form), bracketed by HIP events on this stream when timing
+    if (timing) SGO_HIP(hipEventRecord(x->h.ev0, st));
+    CK(launch_advance_split(c.S, c.G * c.E, &c.dstatus->n_leaf, c.pos, c.leafIn, c.leafMv, nullptr, c.pos, c.leafOut, c.legal,
+                            c.leafOut, nullptr, st));
+    if (timing) SGO_HIP(hipEventRecord(x->h.ev1, st));
     SGO_HIP(hipMemcpyAsync(c.hstatus, c.dstatus, sizeof(DevStatus), hipMemcpyDeviceToHost, st));
-    SGO_HIP(hipStreamSynchronize(st));
+    return SGO_OK;
+}
+
+static void read_status(sgo_ctx *x, sgo_status *out) {
+    Ctx &c = x->c;
     const DevStatus &d = *c.hstatus;
-    if (d.n_leaf > 0) {
-        float ms = 0;
-        if (hipEventElapsedTime(&ms, x->h.ev0, x->h.ev1) == hipSuccess) {
-            x->h.adv_ms += ms; x->h.adv_launches += 1; x->h.adv_positions += d.n_leaf;
-        }
-    }
     out->n_eval = d.n_eval; out->n_records = d.n_records; out->n_active = d.n_active; out->n_done = d.n_done;
     out->error = d.error; out->error_game = d.error_game; out->total_moves = (int64_t)d.total_moves;
     out->total_evals = (int64_t)d.total_evals; out->none_events = (int64_t)d.none_events;
     c.last_n_eval = d.n_eval;
+}
+
+int sgo_step(sgo_ctx *x, const float *d_policy, const float *d_value, int sym_k, void *stream, sgo_status *out) {
+    if (!x || !out || sym_k < 0 || sym_k > 7) { set_error("sgo_step: bad argument"); return SGO_ERR_ARG; }
+    Ctx &c = x->c;
+    hipStream_t st = (hipStream_t)stream;
+    if (c.last_n_eval > 0 && (!d_policy || !d_value)) {
+        set_error("sgo_step: the previous step listed positions to evaluate; policy/value are required");
+        return SGO_ERR_STATE;
+    }
+    const int rc = step_enqueue(x, d_policy, d_value, sym_k, nullptr, st, true);
+    if (rc != SGO_OK) return rc;
+    SGO_HIP(hipStreamSynchronize(st));
+    if (c.hstatus->n_leaf > 0) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, x->h.ev0, x->h.ev1) == hipSuccess) {
+            x->h.adv_ms += ms; x->h.adv_launches += 1; x->h.adv_positions += c.hstatus->n_leaf;
+        }
+    }
+    read_status(x, out);
     return SGO_OK;
+}
+
+int sgo_step_enqueue(sgo_ctx *x, const float *d_policy, const float *d_value, const int32_t *d_sym_k, void *stream) {
+    if (!x || !d_policy || !d_value || !d_sym_k) { set_error("sgo_step_enqueue: bad argument"); return SGO_ERR_ARG; }
+    return step_enqueue(x, d_policy, d_value, 0, d_sym_k, (hipStream_t)stream, false);
+}
+
+int sgo_step_status(sgo_ctx *x, sgo_status *out) {
+    if (!x || !out) { set_error("sgo_step_status: bad argument"); return SGO_ERR_ARG; }
+    read_status(x, out);
+    return SGO_OK;
+}
+
+int sgo_eval_list(sgo_ctx *x, const uint32_t **d_records, const int32_t **d_index, const int32_t **d_models) {
+    if (!x) { set_error("sgo_eval_list: bad argument"); return SGO_ERR_ARG; }
+    if (d_records) *d_records = x->c.pos;
+    if (d_index) *d_index = x->c.evalIdx;
+    if (d_models) *d_models = x->c.evalModel;
+    return x->c.G * x->c.E;
 }
 
 int sgo_eval_models(sgo_ctx *x, int cap, int32_t *models) {

@@ -244,69 +244,6 @@ __global__ __launch_bounds__(64) void k_board_advance_rows(int n, const int *n_d
     if (status && y == 0) status[i] = st ? st : mover;
 }
 
-// board_advance FUSED with nn_input_pack for the engine's leaf list: the half-wave that plays the move also emits the
-// child's network-input row (fp16, NHWC with the channels zero-padded to 32, symmetry k applied on the gather side), so the
-// child record is not read again by a pack kernel.  The sixteen plane bits of a point come from registers for the new pair
-// (plane words held by lanes 0..NW-1 of the half, fetched with ds_bpermute) and from the parent record for the history
-// (parent planes 0..13 = child planes 2..15; those lines were just loaded by the history move of the same half-wave).
-// Output mapping: four lanes write the four 16-byte quarters of one point, so a half-wave store instruction covers eight
-// consecutive points = 512 contiguous bytes.  nn_row[i] = row of leaf i in the evaluation list.
-template <int S>
-__global__ __launch_bounds__(64) void k_board_advance_rows_nn(int n, const int *n_dev, const uint32_t *in, const int32_t *in_idx,
-                                                              const int32_t *moves, uint32_t *out, const int32_t *out_idx,
-                                                              uint32_t *legal, const int32_t *legal_idx, const int32_t *nn_row,
-                                                              int k, _Float16 *nn_out) {
-    using G = Geo<S>;
-    if (n_dev) n = *n_dev;
-    const int half = threadIdx.x >> 5, y = threadIdx.x & 31;
-    const int i0 = blockIdx.x * 2;
-    if (i0 >= n) return;
-    const bool live = i0 + half < n;                 // the second half of the last wave idles but keeps the wave converged
-    const int i = live ? i0 + half : i0;
-    const uint32_t *src = in + (size_t)in_idx[i] * G::RW;
-    uint32_t *dst = out + (size_t)out_idx[i] * G::RW;
-    uint32_t *lg = legal + (size_t)legal_idx[i] * G::NW;
-    // ---- the ply itself (same code path as k_board_advance_rows)
-    Board_rows_result<S> r;
-    rows_advance_keep<S>(src, live ? dst : nullptr, moves[i], live ? lg : nullptr, half, y, r);
-    // ---- network input row of the child.  Each lane (board row y) publishes the 16 plane rows of ITS row -- the new pair
-    //      from registers, the history from the parent record -- in the network's relative plane order as one 64-byte LDS
-    //      record [half][row][plane]; a point's eight planes of one output quarter are then two ds_read_b128.
-    __shared__ __attribute__((aligned(16))) uint32_t tab[2][32][16];
-    const int flip = r.child_white ? 1 : 0;          // planes relative to the side to move: relative c = absolute c ^ flip
-    {
-        uint32_t *mine = &tab[half][y][0];
-        mine[0 ^ flip] = r.rb;
-        mine[1 ^ flip] = r.rw;
-#pragma unroll
-        for (int a = 2; a < 16; a++) mine[a ^ flip] = rows::load_row<S>(src + (a - 2) * G::NW, y);   // 0 for padding rows
-    }
-    __syncthreads();
-    char *orow = reinterpret_cast<char *>(nn_out + (size_t)nn_row[i] * G::N * 32);
-    const int q = y & 3;
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-#pragma unroll 2
-    for (int p0 = 0; p0 < G::N; p0 += 8) {
-        const int pt = p0 + (y >> 2);
-        const int pp = pt < G::N ? pt : G::N - 1;
-        const int pi = pp / S, pj = pp - pi * S;
-        int si, sj;
-        sym_src(S, k, pi, pj, si, sj);
-        u32x4 o = {0u, 0u, 0u, 0u};
-        if (q < 2) {
-            const u32x4 lo = *reinterpret_cast<const u32x4 *>(&tab[half][si][q * 8]);
-            const u32x4 hi = *reinterpret_cast<const u32x4 *>(&tab[half][si][q * 8 + 4]);
-            // bit sj of plane c -> fp16 1.0 (0x3C00) or 0.0; two planes per dword
-            o[0] = ((lo[0] >> sj) & 1u) * 0x3C00u | ((lo[1] >> sj) & 1u) * 0x3C000000u;
-            o[1] = ((lo[2] >> sj) & 1u) * 0x3C00u | ((lo[3] >> sj) & 1u) * 0x3C000000u;
-            o[2] = ((hi[0] >> sj) & 1u) * 0x3C00u | ((hi[1] >> sj) & 1u) * 0x3C000000u;
-            o[3] = ((hi[2] >> sj) & 1u) * 0x3C00u | ((hi[3] >> sj) & 1u) * 0x3C000000u;
-        } else if (q == 2) {
-            o[0] = flip ? 0xBC00u : 0x3C00u;         // the colour plane: -1.0 / +1.0
-        }
-        if (live && pt < G::N) *reinterpret_cast<u32x4 *>(orow + (size_t)pt * 64 + q * 16) = o;
-    }
-}
 
 template <int S>
 __global__ __launch_bounds__(256) void k_legal(int n, const uint32_t *packed, const int32_t *idx, uint32_t *legal) {
@@ -603,55 +540,6 @@ int launch_advance_split(int S, int n_max, const int *d_n, const uint32_t *d_in,
     return SGO_OK;
 }
 
-// nn_input_pack for a device-counted list of (record, output row) pairs -- the root evaluations of a fused engine step,
-// whose leaves were packed by k_board_advance_rows_nn.  fp16 NHWC-32 only.  Four lanes per point, like the fused kernel.
-template <int S>
-__global__ __launch_bounds__(256) void k_nn_pack_rows(const int *n_dev, const uint32_t *packed, const int32_t *idx, const int32_t *rows_,
-                                                      int k, _Float16 *out) {
-    using G = Geo<S>;
-    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-    const int n = *n_dev;
-    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (long)n * G::N * 4) return;
-    const int e = (int)(gid / (G::N * 4)), rem = (int)(gid - (long)e * G::N * 4), pt = rem >> 2, q = rem & 3;
-    const int pi = pt / S, pj = pt - pi * S;
-    int si, sj;
-    sym_src(S, k, pi, pj, si, sj);
-    const int sp = si * S + sj;
-    const uint32_t *rec = packed + (size_t)idx[e] * G::RW;
-    const int flip = white_to_play<S>(rec) ? 1 : 0;
-    h8 v;
-#pragma unroll
-    for (int c = 0; c < 8; c++) v[c] = (_Float16)0.0f;
-    if (q < 2) {
-#pragma unroll
-        for (int c = 0; c < 8; c++) v[c] = (_Float16)(float)((rec[((q * 8 + c) ^ flip) * G::NW + (sp >> 5)] >> (sp & 31)) & 1u);
-    } else if (q == 2) {
-        v[0] = (_Float16)(flip ? -1.0f : 1.0f);
-    }
-    *reinterpret_cast<h8 *>(out + ((size_t)rows_[e] * G::N + pt) * 32 + q * 8) = v;
-}
-
-bool advance_rows_nn_fits(int n_max) { return n_max <= ROWS_MAX_LEAVES; }
-
-int launch_advance_rows_nn(int S, int n_max, const int *d_n, const uint32_t *d_in, const int32_t *d_in_idx, const int32_t *d_moves,
-                           uint32_t *d_out, const int32_t *d_out_idx, uint32_t *d_legal, const int32_t *d_legal_idx,
-                           const int32_t *d_nn_row, int k, void *d_nn_out, hipStream_t st) {
-    if (n_max <= 0) return SGO_OK;
-    SGO_DISPATCH(S, (k_board_advance_rows_nn<kS><<<dim3(cdiv(n_max, 2)), dim3(64), 0, st>>>(
-                        n_max, d_n, d_in, d_in_idx, d_moves, d_out, d_out_idx, d_legal, d_legal_idx, d_nn_row, k, (_Float16 *)d_nn_out)));
-    SGO_HIP(hipGetLastError());
-    return SGO_OK;
-}
-
-int launch_nn_pack_rows(int S, int n_max, const int *d_n, const uint32_t *d_packed, const int32_t *d_idx, const int32_t *d_rows, int k,
-                        void *d_out, hipStream_t st) {
-    if (n_max <= 0) return SGO_OK;
-    SGO_DISPATCH(S, (k_nn_pack_rows<kS><<<dim3(cdiv((long)n_max * kS * kS * 4, 256)), dim3(256), 0, st>>>(
-                        d_n, d_packed, d_idx, d_rows, k, (_Float16 *)d_out)));
-    SGO_HIP(hipGetLastError());
-    return SGO_OK;
-}
 
 int launch_advance_legal(int S, int n, const uint32_t *d_in, const int32_t *d_in_idx, const int32_t *d_moves,
                          const int32_t *d_colors, uint32_t *d_out, const int32_t *d_out_idx, uint32_t *d_legal,

@@ -58,7 +58,7 @@ class MoveRecord(dict):
 class SelfPlayEngine(object):
     def __init__(self, net, size=None, n_games=None, sims=None, energy=None, stop_exploration=None, num_moves=None,
                  komi=None, self_play=True, dirichlet_alpha=None, dirichlet_epsilon=None, blocks_per_game=0,
-                 device=0, symmetry="random1", layout="nhwc", dtype="fp16", seed=0, raise_on_error=True, fused_pack=True,
+                 device=0, symmetry="random1", layout="nhwc", dtype="fp16", seed=0, raise_on_error=True, packed=True,
                  net2=None):
         """net2: a second net turns the slots into two-model EVALUATION games (evaluate_worker.py:137: model1 = `net`,
         model2 = `net2`, one tree per player, no Dirichlet noise); start them with start_eval_games."""
@@ -102,7 +102,15 @@ class SelfPlayEngine(object):
         max_eval = self.G * self.E
         tdt = torch.float16 if self.dtype == 0 else torch.float32
         shape = {0: (max_eval, self.S, self.S, 17), 1: (max_eval, 17, self.S, self.S), 2: (max_eval, self.S, self.S, 32)}[self.layout]
-        self.nn_in = torch.zeros(shape, dtype=tdt, device=self.device)
+        # The resident net reads the evaluation list as PACKED RECORDS (net.FusedInferenceNet.predict_packed -> sgo_stem_packed_dev:
+        # the stem kernel expands the bit-planes in LDS), so no network-input tensor exists on that route; nets that take board
+        # tensors (stub nets, plain torch modules, fp32) get them from sgo_collect (k_nn_pack) into nn_in.
+        nets = [net] + ([net2] if net2 is not None else [])
+        self.packed = bool(packed) and self.dtype == 0 and all(getattr(m, "packed_ok", False) for m in nets)
+        self.nn_in = None if self.packed else torch.zeros(shape, dtype=tdt, device=self.device)
+        rec, idx, mod = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _lib.check(self.lib.sgo_eval_list(self.ctx, C.byref(rec), C.byref(idx), C.byref(mod)), "sgo_eval_list")
+        self._rec_ptr, self._idx_ptr = rec.value, idx.value
         self.status = _lib.Status()
         self._policy = None
         self._value = None
@@ -114,10 +122,6 @@ class SelfPlayEngine(object):
         self.n_net_positions = 0
         self.n_model_positions = [0, 0]    # two-model games: positions evaluated by model1 / model2
         self._primed = False
-        # nn_input_pack fused into board_advance (sgo_step_fused): the step that lists positions also writes their network
-        # input, for the fused net's layout (fp16 NHWC-32) and one symmetry per batch
-        self.fused_pack = bool(fused_pack) and self.layout == 2 and self.dtype == 0 and symmetry != "avg8"
-        self._k_packed = 0             # symmetry the rows waiting in nn_in were packed with
         self.raise_on_error = raise_on_error   # False: a failing slot (e.g. block pool exhausted) is left to the caller
 
     def close(self):
@@ -198,19 +202,34 @@ class SelfPlayEngine(object):
             return self.pyrng.randrange(7)  # choice(SYMMETRIES), symmetry.py:128
         return int(self.symmetry)
 
-    def _forward(self, n, k, packed=False):
+    def _index_view(self):
+        """The device-side evaluation list (record indices, int32 [G * E]) as a torch tensor over the engine's own memory."""
+        if getattr(self, "_idx_t", None) is None:
+            class _Mem(object):
+                pass
+            m = _Mem()
+            m.__cuda_array_interface__ = {"shape": (self.G * self.E,), "typestr": "<i4", "data": (self._idx_ptr, False), "version": 2}
+            self._idx_t = self.torch.as_tensor(m, device=self.device)
+        return self._idx_t
+
+    def _forward(self, n, k):
         torch = self.torch
-        if not packed:
-            _lib.check(self.lib.sgo_collect(self.ctx, C.c_int(k), C.c_int(self.layout), C.c_int(self.dtype),
-                                            _lib.ptr(self.nn_in), _lib.stream_ptr()), "sgo_collect")
-        x = self.nn_in[:n]
-        if self.layout == 1:
-            x = x.permute(0, 2, 3, 1)  # present the reference's NHWC view
         self.n_net_calls += 1
         self.n_net_positions += n
-        if not self.two_model:
-            p, v = self.net.predict_on_batch(x)
-            return p.to(torch.float32), v.to(torch.float32).reshape(n)
+        if self.packed:
+            if not self.two_model:
+                p, v = self.net.predict_packed(self._rec_ptr, self._idx_ptr, n, k)
+                return p.to(torch.float32), v.to(torch.float32).reshape(n)
+            x = None
+        else:
+            _lib.check(self.lib.sgo_collect(self.ctx, C.c_int(k), C.c_int(self.layout), C.c_int(self.dtype),
+                                            _lib.ptr(self.nn_in), _lib.stream_ptr()), "sgo_collect")
+            x = self.nn_in[:n]
+            if self.layout == 1:
+                x = x.permute(0, 2, 3, 1)  # present the reference's NHWC view
+            if not self.two_model:
+                p, v = self.net.predict_on_batch(x)
+                return p.to(torch.float32), v.to(torch.float32).reshape(n)
         # two-model games: every row of the list belongs to the model that is to move in its game
         ids = np.zeros(n, dtype=np.int32)
         _lib.check(self.lib.sgo_eval_models(self.ctx, C.c_int(n), _lib.ptr(ids)), "sgo_eval_models")
@@ -222,12 +241,16 @@ class SelfPlayEngine(object):
                 continue
             self.n_model_positions[m] += len(idx)
             if len(idx) == n:
-                p, v = net.predict_on_batch(x)
+                p, v = net.predict_packed(self._rec_ptr, self._idx_ptr, n, k) if self.packed else net.predict_on_batch(x)
                 pol.copy_(p)
                 val.copy_(v.reshape(n))
                 continue
             it = torch.from_numpy(idx).to(self.device)
-            p, v = net.predict_on_batch(x.index_select(0, it).contiguous())
+            if self.packed:
+                sub = self._index_view()[:n].index_select(0, it).contiguous()       # this model's rows of the list
+                p, v = net.predict_packed(self._rec_ptr, sub.data_ptr(), len(idx), k)
+            else:
+                p, v = net.predict_on_batch(x.index_select(0, it).contiguous())
             pol.index_copy_(0, it, p.to(torch.float32))
             val.index_copy_(0, it, v.to(torch.float32).reshape(-1))
         return pol, val
@@ -248,11 +271,6 @@ class SelfPlayEngine(object):
                 pol = (pol / 8.0).contiguous()
                 val = (val / 8.0).contiguous()
                 k_used = 0
-            elif self.fused_pack:
-                k_used = self._k_packed          # the rows were written by the previous sgo_step_fused
-                pol, val = self._forward(n, k_used, packed=True)
-                pol = pol.contiguous()
-                val = val.contiguous()
             else:
                 k_used = self._draw_k()
                 pol, val = self._forward(n, k_used)
@@ -262,14 +280,7 @@ class SelfPlayEngine(object):
             pp, vp = _lib.ptr(pol), _lib.ptr(val)
         else:
             pp, vp, k_used = None, None, 0
-        if self.fused_pack:
-            next_k = self._draw_k()              # one symmetry for the batch this step lists (symmetry.py:127-132)
-            _lib.check(self.lib.sgo_step_fused(self.ctx, pp, vp, C.c_int(k_used), C.c_int(next_k), _lib.ptr(self.nn_in),
-                                               _lib.stream_ptr(), C.byref(self.status)), "sgo_step_fused")
-            self._k_packed = next_k
-        else:
-            _lib.check(self.lib.sgo_step(self.ctx, pp, vp, C.c_int(k_used), _lib.stream_ptr(), C.byref(self.status)),
-                       "sgo_step")
+        _lib.check(self.lib.sgo_step(self.ctx, pp, vp, C.c_int(k_used), _lib.stream_ptr(), C.byref(self.status)), "sgo_step")
         self._primed = True
         self.n_steps += 1
         if self.status.error and self.raise_on_error:

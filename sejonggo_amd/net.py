@@ -160,6 +160,13 @@ class FusedInferenceNet(object):
         w[:, :17] = f.stem.weight
         self.stem_w, self.stem_b = cw(w), f.stem.bias.to(dev, dtype).contiguous()
         self.stem_pad = f.stem.padding
+        # the stem as sgo_stem_packed_dev wants it: [256][10 taps][16 stone planes] fp16 (tap = dy * 3 + dx, tap 9 zero) and the
+        # colour plane folded into a per-position bias term: under the 'valid' stem every tap of plane 16 (= +-1 everywhere) is on
+        # the board, so it contributes c * sum_taps w[k][16][tap] to every output pixel
+        w10 = torch.zeros(self.channels, 10, 16)
+        w10[:, :9, :] = f.stem.weight[:, :16].permute(0, 2, 3, 1).reshape(self.channels, 9, 16)
+        self.stem_w10 = w10.to(dev, dtype).contiguous()
+        self.stem_wcol = f.stem.weight[:, 16].reshape(self.channels, 9).sum(dim=1).to(dev, torch.float32).contiguous()
         self.blocks = [(cw(b.conv1.weight), b.conv1.bias.to(dev, dtype).contiguous(),
                         cw(b.conv2.weight), b.conv2.bias.to(dev, dtype).contiguous()) for b in f.blocks]
         hw = torch.cat([f.p_conv.weight.reshape(2, -1), f.v_conv.weight.reshape(2, -1)], 0)      # [4, C]
@@ -244,11 +251,31 @@ class FusedInferenceNet(object):
         h = (rounds * self.n_cu * 256) // t2          # positions whose tiles fit the whole rounds
         return h if 0 < h < n else 0
 
+    @property
+    def packed_ok(self):
+        """True when the stem can read packed position records (sgo_stem_packed_dev): the reference's shape, 'valid' stem."""
+        pad0 = self.stem_pad[0] if isinstance(self.stem_pad, (tuple, list)) else self.stem_pad
+        return self.fused_conv and self.channels == 256 and pad0 == 0 and self.t <= 19 and self.size in self._lib.SUPPORTED_SIZES
+
+    @torch.no_grad()
+    def predict_packed(self, records_ptr, index_ptr, n, k=0, k_dev_ptr=None):
+        """The engine's route: rows = packed position records on the device (`records_ptr`: base of a record array,
+        `index_ptr`: int32 device list of n record indices or None for records 0..n-1), evaluated under symmetry k (or the
+        device int at `k_dev_ptr`).  No network-input tensor is materialised: the stem kernel expands the bit-planes in LDS.
+        Returns (policy [n, A] float32, value [n, 1] float32) like predict_on_batch."""
+        y = torch.empty((n, self.channels, self.t, self.t), dtype=torch.float16, device=self.device, memory_format=torch.channels_last)
+        self._lib.check(self.lib.sgo_stem_packed_dev(self.size, n, records_ptr, index_ptr, int(k), k_dev_ptr, self.stem_w10.data_ptr(),
+                                                     self.stem_b.data_ptr(), self.stem_wcol.data_ptr(), y.data_ptr(),
+                                                     torch.cuda.current_stream().cuda_stream), "sgo_stem_packed_dev")
+        return self._tower_and_heads(y)
+
     def _forward(self, X):
-        n = X.shape[0]
         x = X.permute(0, 3, 1, 2)                                 # NCHW view of channels-last memory
         pad0 = self.stem_pad[0] if isinstance(self.stem_pad, (tuple, list)) else self.stem_pad
-        y = self._conv(x, self.stem_w, self.stem_b, pad0)
+        return self._tower_and_heads(self._conv(x, self.stem_w, self.stem_b, pad0))
+
+    def _tower_and_heads(self, y):
+        n = y.shape[0]
         for (w1, b1, w2, b2) in self.blocks:
             z = self._conv(y, w1, b1, 1)
             y = self._conv(z, w2, b2, 1, skip=y)

@@ -1,8 +1,8 @@
 """GPU parity at the sizes BASELINE.json names (VERDICT r2 "Next round" item 1):
 
 * pi / value tolerance of the resident fp16 net against its own fp32 torch module for the reference's 20-block / 256-filter
-  topology at 19x19 (model.py:55-95, conf.py N_RESIDUAL_BLOCKS) and the 4-block / 256 net of config 2 at 9x9, on input rows
-  the engine's own fused board_advance + pack kernel wrote, under all 8 symmetries, at plies from the opening to a full board;
+  topology at 19x19 (model.py:55-95, conf.py N_RESIDUAL_BLOCKS) and the 4-block / 256 net of config 2 at 9x9, on packed
+  records board_advance itself wrote, read by the stem kernel under all 8 symmetries, from the opening to a nearly full board;
 * the tower convolution at the headline LAUNCH (8 192 positions x 17 x 17, with skip) against fp32 on sampled tiles;
 * config 2's batch shape (256 games x 9x9 x 200 sims) against the oracle on sampled slots;
 * go_game.GoGame.do_move replaying a scripted golden game on the device.
@@ -26,95 +26,78 @@ def L():
     return _lib
 
 
-def _rows_from_the_engine(fnet, S, plies, G=16):
-    """Plays G games with a thin search on the real net and returns {ply: (rows fp16 [n,S,S,32], symmetry k)}: the input
-    rows of the leaf batches listed at those plies, as k_board_advance_rows_nn left them in the engine's input buffer.  The
-    symmetry of the batch cycles through all 8 from step to step."""
-    from sejonggo_amd.engine import SelfPlayEngine
-    eng = SelfPlayEngine(fnet, size=S, n_games=G, sims=8, energy=8, stop_exploration=30, komi=5.5, symmetry=0, seed=5)
-    assert eng.fused_pack
-    eng.start_games(np.arange(G))
-    want = sorted(plies)
-    got = {}
-    step = 0
-    while want and step < 4 * (want[-1] + 2) + 8:
-        eng.symmetry = step % 8                    # the symmetry the NEXT listed batch is packed with
-        st = eng.step()
-        step += 1
-        if st.n_records >= G:
-            eng.drain()
-        ply = int(st.total_moves) // G
-        # a leaf batch (G * 8 rows; a root batch after a move has G rows) at a wanted ply
-        if ply >= want[0] and st.n_eval >= 4 * G:
-            got[want.pop(0)] = (eng.nn_in[:st.n_eval].clone(), eng._k_packed, ply)
-        if st.n_active < G // 2:
-            break
-    eng.close()
-    return got
+def _playout_records(L, S, n, ply, seed):
+    """n packed position records after `ply` seeded random legal moves each (passes rare), written by board_advance itself
+    (sgo_advance_legal_dev), on the device."""
+    import torch
+    lib = L.load()
+    A, NW, RW = S * S + 1, lib.sgo_plane_words(S), lib.sgo_packed_words(S)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    cur = torch.zeros((n, RW), dtype=torch.int32, device="cuda")
+    nxt = torch.zeros_like(cur)
+    legal = torch.full((n, NW), -1, dtype=torch.int32, device="cuda")
+    legal[:, NW - 1] = (1 << ((A - 1) % 32 + 1)) - 1
+    shifts = torch.arange(32, device="cuda", dtype=torch.int32)
+    st = L.stream_ptr()
+    for _ in range(ply):
+        bits = ((legal.unsqueeze(-1) >> shifts) & 1).reshape(n, NW * 32)[:, :A].float()
+        bits[:, A - 1] = 0.01
+        mv = torch.multinomial(bits, 1, generator=g).reshape(-1).to(torch.int32)
+        L.check(lib.sgo_advance_legal_dev(S, n, L.ptr(cur), None, L.ptr(mv), None, L.ptr(nxt), None, L.ptr(legal), None, st))
+        cur, nxt = nxt, cur
+    return cur
 
 
 @pytest.mark.parametrize("S,blocks,plies", [(19, 20, (0, 30, 120, 250)), (9, 4, (0, 10, 30, 60))],
                          ids=["19x19_20block_256", "9x9_4block_256"])
 def test_baseline_nets_match_fp32_within_the_stated_tolerance(L, S, blocks, plies):
+    """The resident fp16 net on the engine's own route (packed records -> sgo_stem_packed_dev -> tower kernel -> heads) against
+    the fp32 torch module of the same weights on the 17-plane tensor of the same records: the reference's 20-block / 256-filter
+    topology at 19x19 and config 2's 4-block net at 9x9; 64 positions per ply from the empty board to a nearly full one, every
+    one of the 8 symmetries on every batch."""
     import torch
     from sejonggo_amd.net import build_fused_net
+    lib = L.load()
     fnet, ref = build_fused_net(S, blocks, 256, name="parity", seed=11)
+    assert fnet.packed_ok
     ref = ref.cuda().float()
-    batches = _rows_from_the_engine(fnet, S, plies)
-    assert len(batches) >= 3, "the thin-search games ended before the later plies: %r" % sorted(batches)
-    seen_k = set()
+    n = 64
     worst_p = worst_v = 0.0
-    n_rows = 0
     report = []
-    for want_ply in sorted(batches):
-        rows, k, ply = batches[want_ply]
-        seen_k.add(k)
-        assert rows.shape[0] >= 64
-        # the rows are what the kernel wrote: 16 stone planes of 0/1, the colour plane +-1, 15 zero channels
-        assert float(rows[..., 17:].abs().max()) == 0.0 and bool(((rows[..., :16] == 0) | (rows[..., :16] == 1)).all())
-        assert bool((rows[..., 16].abs() == 1).all())
-        stones = float(rows[..., 0:2].sum()) / rows.shape[0]
-        p1, v1 = fnet.predict_on_batch(rows)
-        p0, v0 = ref.predict_on_batch(rows[..., :17].float())
-        dp, dv = float((p1 - p0).abs().max()), float((v1.reshape(-1) - v0.reshape(-1)).abs().max())
-        report.append((ply, k, rows.shape[0], round(stones, 1), dp, dv))
-        worst_p, worst_v = max(worst_p, dp), max(worst_v, dv)
-        n_rows += rows.shape[0]
-    # every symmetry once more on ONE late batch through the un-fused pack (k_nn_pack, the reference's transforms):
-    # transformed boards are just other inputs to the nets, and the fused rows of the cycle above already cover several k
-    print("\nNET_TOLERANCE S=%d blocks=%d rows=%d max|dp|=%.3e max|dv|=%.3e symmetries=%s per-batch(ply,k,n,stones,dp,dv)=%s"
-          % (S, blocks, n_rows, worst_p, worst_v, sorted(seen_k), report))
+    for ply in plies:
+        recs = _playout_records(L, S, n, ply, seed=1000 + ply)
+        for k in range(8):
+            x = torch.zeros((n, S, S, 17), dtype=torch.float32, device="cuda")
+            L.check(lib.sgo_nn_pack_dev(S, n, L.ptr(recs), None, k, 0, 1, L.ptr(x), L.stream_ptr()))
+            p0, v0 = ref.predict_on_batch(x)
+            p1, v1 = fnet.predict_packed(recs.data_ptr(), None, n, k)
+            assert p1.shape == (n, S * S + 1) and v1.shape == (n, 1)
+            dp, dv = float((p1 - p0).abs().max()), float((v1 - v0).abs().max())
+            if k == 0:
+                report.append((ply, round(float(x[..., :2].sum()) / n, 1), dp, dv))
+            worst_p, worst_v = max(worst_p, dp), max(worst_v, dv)
+    print("\nNET_TOLERANCE S=%d blocks=%d positions=%d x 8 symmetries: max|dp|=%.3e max|dv|=%.3e; per ply (ply, stones, dp, dv at k=0): %s"
+          % (S, blocks, n * len(plies), worst_p, worst_v, report))
     assert worst_p <= P_TOL and worst_v <= V_TOL, report
-    assert n_rows >= 64 * 3
 
 
-def test_baseline_nets_under_all_eight_symmetries(L):
-    """One late-opening batch of the 20-block 19x19 net packed under each of the 8 symmetries by the engine's own kernels
-    (fused rows for k = 0..7): fp16 net vs fp32 module on each, and the inverse-permuted policies agree with the identity's
-    within twice the tolerance (the net is not equivariant, so only the fp32 pairing is tight)."""
+def test_packed_route_equals_the_tensor_route_of_the_same_net(L):
+    """FusedInferenceNet.predict_packed (stem from records, colour plane folded into the bias) against predict_on_batch of the
+    SAME fp16 net on the channel-padded tensor (k_stem, the route of put_predict_request callers): the two stems differ only in
+    summation order, so policies and values agree far inside the fp32 tolerance."""
     import torch
-    from sejonggo_amd.engine import SelfPlayEngine
     from sejonggo_amd.net import build_fused_net
-    S, G = 19, 8
-    fnet, ref = build_fused_net(S, 20, 256, name="parity", seed=11)
-    ref = ref.cuda().float()
-    worst_p = worst_v = 0.0
-    for k in range(8):
-        eng = SelfPlayEngine(fnet, size=S, n_games=G, sims=8, energy=8, stop_exploration=30, komi=5.5, symmetry=k, seed=5)
-        eng.start_games(np.arange(G))
-        rows = None
-        for _ in range(2 * 12 + 2):
-            st = eng.step()
-            if st.n_eval >= 4 * G:
-                rows = eng.nn_in[:st.n_eval].clone()
-        eng.close()
-        assert rows is not None and rows.shape[0] >= 32
-        p1, v1 = fnet.predict_on_batch(rows)
-        p0, v0 = ref.predict_on_batch(rows[..., :17].float())
-        worst_p = max(worst_p, float((p1 - p0).abs().max()))
-        worst_v = max(worst_v, float((v1.reshape(-1) - v0.reshape(-1)).abs().max()))
-    print("\nNET_TOLERANCE_8SYM max|dp|=%.3e max|dv|=%.3e" % (worst_p, worst_v))
-    assert worst_p <= P_TOL and worst_v <= V_TOL
+    lib = L.load()
+    S = 19
+    fnet, _ = build_fused_net(S, 2, 256, name="parity", seed=3)
+    recs = _playout_records(L, S, 96, 80, seed=77)
+    for k in (0, 3, 6):
+        x = torch.zeros((96, S, S, 32), dtype=torch.float16, device="cuda")
+        L.check(lib.sgo_nn_pack_dev(S, 96, L.ptr(recs), None, k, 2, 0, L.ptr(x), L.stream_ptr()))
+        p0, v0 = fnet.predict_on_batch(x)
+        p1, v1 = fnet.predict_packed(recs.data_ptr(), None, 96, k)
+        assert float((p1 - p0).abs().max()) <= 5e-4 and float((v1 - v0).abs().max()) <= 2e-3
 
 
 def test_tower_conv_at_the_headline_launch(L):

@@ -328,30 +328,64 @@ class _SymNet(object):
         return pol, val
 
 
-class _Padded32(object):
-    """A stub net behind the fused inference net's input contract (fp16 NHWC with the channels zero-padded to 32): makes
-    the engine take the fused board_advance + nn_input_pack step (sgo_step_fused) while the evaluation stays the
-    rounding-free hash of the 17 real planes -- any wrong bit in a packed row changes the game."""
-    in_channels = 32
+class _PackedProbe(object):
+    """A stub net behind the resident net's PACKED-RECORD input contract (engine route: net.predict_packed -> sgo_stem_packed_dev),
+    built so that the evaluation stays rounding-free: the real stem kernel runs with 0/1 weights that copy plane c of tap t into
+    output channel 16 t + c (and the colour term into channel 144), the full S x S x 17 board tensor is re-assembled from those
+    (S-2)^2 x 145 values -- every board point is under some tap of some output pixel -- and handed to the hash net.  Any wrong bit,
+    tap, symmetry, colour flip or list index in the kernel changes the game."""
+    packed_ok = True
 
-    def __init__(self, net):
-        self.net, self.name = net, net.name
+    def __init__(self, net, S):
+        import torch
+        from sejonggo_amd import _lib
+        self.net, self.name, self.S, self.t = net, net.name, S, S - 2
+        self._lib, self.lib = _lib, _lib.require_gpu()
+        w10 = torch.zeros(256, 10, 16)
+        for t in range(9):
+            for c in range(16):
+                w10[16 * t + c, t, c] = 1.0
+        self.w10 = w10.half().cuda().contiguous()
+        self.bias = torch.zeros(256, dtype=torch.float16, device="cuda")
+        wcol = torch.zeros(256)
+        wcol[144] = 1.0                                   # relu(+1) = 1 black to play, relu(-1) = 0 white to play
+        self.wcol = wcol.cuda().contiguous()
+        ys = torch.arange(S)
+        o = (ys - 1).clamp(0, S - 3)                      # an output pixel row whose window covers board row y, and the tap row
+        d = ys - o
+        self.oy, self.ox = o.cuda()[:, None].expand(S, S), o.cuda()[None, :].expand(S, S)
+        self.tap = (d[:, None] * 3 + d[None, :]).cuda()
+
+    def predict_packed(self, records_ptr, index_ptr, n, k=0, k_dev_ptr=None):
+        import torch
+        S, t = self.S, self.t
+        y = torch.full((n, t, t, 256), 7.0, dtype=torch.float16, device="cuda")
+        self._lib.check(self.lib.sgo_stem_packed_dev(S, n, records_ptr, index_ptr, int(k), k_dev_ptr, self.w10.data_ptr(),
+                                                     self.bias.data_ptr(), self.wcol.data_ptr(), y.data_ptr(),
+                                                     torch.cuda.current_stream().cuda_stream), "sgo_stem_packed_dev")
+        assert float(y[..., 145:].abs().max()) == 0.0
+        g = y[:, self.oy, self.ox, :]                                                  # [n, S, S, 256]
+        ch = (self.tap[..., None] * 16 + torch.arange(16, device="cuda"))[None].expand(n, S, S, 16)
+        planes = torch.gather(g, 3, ch)
+        col = (2.0 * y[:, 0, 0, 144] - 1.0)[:, None, None, None].expand(n, S, S, 1)
+        X = torch.cat([planes, col.to(planes.dtype)], dim=3)
+        assert bool(((X[..., :16] == 0) | (X[..., :16] == 1)).all())
+        return self.net.predict_on_batch(X)
 
     def predict_on_batch(self, X):
-        assert X.shape[-1] == 32 and float(X[..., 17:].abs().max()) == 0.0
-        return self.net.predict_on_batch(X[..., :17])
+        raise AssertionError("the engine must take the packed-record route for this net")
 
 
 @pytest.mark.parametrize("fn", ["async_02.npz", "async_05.npz", "async_07.npz", "async_08.npz"])
-def test_fused_advance_and_pack_reproduces_the_golden_games(L, fn):
-    """sgo_step_fused (one kernel: parent record -> child record + legal bits + the child's network-input row) against the
+def test_packed_record_route_reproduces_the_golden_games(L, fn):
+    """The engine's packed-record route (evaluation list of record indices -> sgo_stem_packed_dev, no input tensor) against the
     reference's goldens: 9x9 and 5x5 games incl. the 'No best leaf' path, 19x19 at 400 sims and at 1 600 sims / 32-leaf rounds."""
     from sejonggo_amd.stub_nets import make_stub
     z = load(fn)
     S = int(z["size"])
-    net = _Padded32(make_stub(bytes(z["net"]).decode(), S))
+    net = _PackedProbe(make_stub(bytes(z["net"]).decode(), S), S)
     eng = _engine(z, net)
-    assert eng.fused_pack and eng.layout == 2
+    assert eng.packed and eng.nn_in is None
     games = eng.run()
     gd = games[0]
     assert len(gd["moves"]) == len(z["move_index"])
@@ -370,9 +404,9 @@ def test_fused_advance_and_pack_reproduces_the_golden_games(L, fn):
     eng.close()
 
 
-@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("packed", [False, True])
 @pytest.mark.parametrize("mode", [1, 2, 3, 4, 5, 6, 7, "avg8"])
-def test_symmetry_modes_equal_the_oracle(L, mode, fused):
+def test_symmetry_modes_equal_the_oracle(L, mode, packed):
     from oracle import oracle as ora
     from sejonggo_amd.engine import SelfPlayEngine
     from sejonggo_amd.stub_nets import make_stub
@@ -381,9 +415,9 @@ def test_symmetry_modes_equal_the_oracle(L, mode, fused):
     rng = np.random.RandomState(21)
     noises = rng.dirichlet([0.03] * (S * S + 1), size=2)
     uni = rng.random_sample((2, nm))
-    eng = SelfPlayEngine(_Padded32(net) if fused else net, size=S, n_games=2, sims=sims, energy=E, stop_exploration=3,
+    eng = SelfPlayEngine(_PackedProbe(net, S) if packed else net, size=S, n_games=2, sims=sims, energy=E, stop_exploration=3,
                          num_moves=nm, komi=5.5, symmetry=mode)
-    assert eng.fused_pack == (fused and mode != "avg8")      # the 8-fold average packs eight times: stand-alone kernel
+    assert eng.packed == packed                               # packed: the stem kernel applies the symmetry (eight passes for avg8)
     eng.start_games([0, 1], noises=noises, uniforms=uni)
     games = eng.run()
     ks = list(range(8)) if mode == "avg8" else [mode]
@@ -799,6 +833,120 @@ def test_stem_conv_kernel(L):
     L.check(lib.sgo_conv3x3_stem_dev(n, h, wd, x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), st))
     ref = torch.relu(F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), b.float()).permute(0, 2, 3, 1))
     assert torch.equal(y.float(), ref)
+
+
+@pytest.mark.parametrize("S", [5, 7, 9, 13, 19])
+def test_stem_packed_kernel(L, S):
+    """sgo_stem_packed_dev (csrc/sgo_stem_packed.hpp): the stem read straight from packed position records.  Reference = torch
+    conv2d in fp32 on the 17-plane tensor that k_nn_pack makes of the same records under the same symmetry (that kernel is
+    pinned against the reference's transforms, test_nn_pack_all_symmetries).  Positions come from seeded random playouts (both
+    sides to move, dense and sparse boards), rows are addressed through a shuffled index list and densely; all 8 symmetries;
+    EXACT on integer weights (any wrong bit, tap, plane flip or symmetry shows), within fp16 rounding on random weights,
+    identical with the symmetry passed by value and through device memory, ragged batch sizes around the 256-pixel tiles."""
+    import torch
+    import torch.nn.functional as F
+    lib = L.load()
+    st = torch.cuda.current_stream().cuda_stream
+    A, NW, RW = S * S + 1, lib.sgo_plane_words(S), lib.sgo_packed_words(S)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(100 + S)
+    n = 700 if S <= 9 else 150
+    cur = torch.zeros((n, RW), dtype=torch.int32, device="cuda")
+    nxt = torch.zeros_like(cur)
+    legal = torch.full((n, NW), -1, dtype=torch.int32, device="cuda")
+    legal[:, NW - 1] = (1 << ((A - 1) % 32 + 1)) - 1
+    shifts = torch.arange(32, device="cuda", dtype=torch.int32)
+    plies = torch.randint(0, 2 * S * S // 3, (n,), device="cuda", generator=g)
+    for ply in range(int(plies.max().item()) + 1):               # record i stops after plies[i] moves (pass from then on)
+        bits = ((legal.unsqueeze(-1) >> shifts) & 1).reshape(n, NW * 32)[:, :A].float()
+        bits[:, A - 1] = 0.02
+        mv = torch.multinomial(bits, 1, generator=g).reshape(-1).to(torch.int32)
+        mv = torch.where(plies > ply, mv, torch.full_like(mv, A - 1))          # finished records pass (and are kept as they are)
+        keep = cur.clone()
+        L.check(lib.sgo_advance_legal_dev(S, n, L.ptr(cur), None, L.ptr(mv), None, L.ptr(nxt), None, L.ptr(legal), None, st))
+        live = (plies > ply)[:, None]
+        cur = torch.where(live, nxt, keep)
+    torch.manual_seed(5 + S)
+    t = S - 2
+    for trial, nn in enumerate([n, 1, 2, max(1, 256 // (t * t)), 256 // (t * t) + 1, 37]):
+        nn = min(nn, n)
+        idx = torch.randperm(n, device="cuda", generator=g)[:nn].to(torch.int32).contiguous()
+        integer = trial % 2 == 0
+        if integer:
+            w = torch.randint(-3, 4, (256, 17, 3, 3), device="cuda").float()
+            b = torch.randint(-5, 6, (256,), device="cuda").float()
+        else:
+            w = (torch.randn(256, 17, 3, 3, device="cuda") * 0.1).half().float()
+            b = torch.randn(256, device="cuda").half().float()
+        w10 = torch.zeros(256, 10, 16, device="cuda")
+        w10[:, :9] = w[:, :16].permute(0, 2, 3, 1).reshape(256, 9, 16)
+        w10 = w10.half().contiguous()
+        wcol = w[:, 16].reshape(256, 9).sum(dim=1).contiguous()
+        bh = b.half().contiguous()
+        for k in range(8):
+            x = torch.zeros((nn, S, S, 17), dtype=torch.float32, device="cuda")
+            L.check(lib.sgo_nn_pack_dev(S, nn, L.ptr(cur), L.ptr(idx), k, 0, 1, L.ptr(x), st))
+            ref = torch.relu(F.conv2d(x.permute(0, 3, 1, 2), w, b)).permute(0, 2, 3, 1)
+            y = torch.full((nn, t, t, 256), 9.0, dtype=torch.float16, device="cuda")
+            L.check(lib.sgo_stem_packed_dev(S, nn, L.ptr(cur), L.ptr(idx), k, None, L.ptr(w10), L.ptr(bh), L.ptr(wcol), L.ptr(y), st))
+            if integer:
+                assert float(ref.max()) < 2048 and torch.equal(y.float(), ref), (S, nn, k)
+            else:
+                err = (y.float() - ref).abs()
+                assert bool((err <= 2e-3 * ref.abs() + 2e-3).all()), (S, nn, k, float(err.max()))
+            kd = torch.tensor([k], dtype=torch.int32, device="cuda")
+            y2 = torch.full_like(y, 3.0)
+            L.check(lib.sgo_stem_packed_dev(S, nn, L.ptr(cur), L.ptr(idx), 0, L.ptr(kd), L.ptr(w10), L.ptr(bh), L.ptr(wcol), L.ptr(y2), st))
+            assert torch.equal(y, y2), (S, nn, k)
+        if nn == n:                                               # dense form (no index list) = the identity list
+            ar = torch.arange(n, dtype=torch.int32, device="cuda")
+            ya, yb = torch.empty((n, t, t, 256), dtype=torch.float16, device="cuda"), torch.empty((n, t, t, 256), dtype=torch.float16, device="cuda")
+            L.check(lib.sgo_stem_packed_dev(S, n, L.ptr(cur), None, 3, None, L.ptr(w10), L.ptr(bh), L.ptr(wcol), L.ptr(ya), st))
+            L.check(lib.sgo_stem_packed_dev(S, n, L.ptr(cur), L.ptr(ar), 3, None, L.ptr(w10), L.ptr(bh), L.ptr(wcol), L.ptr(yb), st))
+            assert torch.equal(ya, yb)
+    assert lib.sgo_stem_packed_dev(S, 1, L.ptr(cur), None, 8, None, L.ptr(w10), L.ptr(bh), L.ptr(wcol), L.ptr(y), st) < 0    # bad symmetry
+    assert lib.sgo_stem_packed_dev(6, 1, L.ptr(cur), None, 0, None, L.ptr(w10), L.ptr(bh), L.ptr(wcol), L.ptr(y), st) < 0    # bad size
+
+
+def test_stem_packed_kernel_at_the_headline_batch(L):
+    """8 192 records x 19 x 19 (the bench's launch) and 32 768 (config 5's): sampled rows against the 17-plane fp32 reference."""
+    import torch
+    import torch.nn.functional as F
+    lib = L.load()
+    S, t = 19, 17
+    st = torch.cuda.current_stream().cuda_stream
+    RW = lib.sgo_packed_words(S)
+    torch.manual_seed(2)
+    base = 4096
+    boards = torch.zeros((base, S, S, 17), dtype=torch.int32, device="cuda")
+    occ = torch.rand((base, S, S, 1), device="cuda")
+    colour = torch.rand((base, S, S, 8), device="cuda") < 0.5
+    dens = torch.rand((base, 1, 1, 1), device="cuda") * 0.7
+    stone = occ < dens
+    boards[..., 0:16:2] = (stone & colour).int()
+    boards[..., 1:16:2] = (stone & ~colour).int()
+    boards[..., 16] = torch.where(torch.rand((base, 1, 1), device="cuda") < 0.5, 1, -1).int()
+    recs = torch.zeros((base, RW), dtype=torch.int32, device="cuda")
+    L.check(lib.sgo_pack_dev(S, base, L.ptr(boards), L.ptr(recs), st))
+    w = (torch.randn(256, 17, 3, 3, device="cuda") * 0.1).half().float()
+    b = torch.randn(256, device="cuda").half().float()
+    w10 = torch.zeros(256, 10, 16, device="cuda")
+    w10[:, :9] = w[:, :16].permute(0, 2, 3, 1).reshape(256, 9, 16)
+    w10, wcol, bh = w10.half().contiguous(), w[:, 16].reshape(256, 9).sum(dim=1).contiguous(), b.half().contiguous()
+    for n in (8192, 32768):
+        idx = torch.randint(0, base, (n,), device="cuda").to(torch.int32)
+        y = torch.full((n, t, t, 256), 9.0, dtype=torch.float16, device="cuda")
+        L.check(lib.sgo_stem_packed_dev(S, n, L.ptr(recs), L.ptr(idx), 5, None, L.ptr(w10), L.ptr(bh), L.ptr(wcol), L.ptr(y), st))
+        rows = sorted(set([0, 1, n - 1, n - 2] + [int(v) for v in np.random.RandomState(n).randint(0, n, size=40)]))
+        ri = torch.tensor(rows, device="cuda")
+        x = torch.zeros((len(rows), S, S, 17), dtype=torch.float32, device="cuda")
+        sub = idx[ri].contiguous()
+        L.check(lib.sgo_nn_pack_dev(S, len(rows), L.ptr(recs), L.ptr(sub), 5, 0, 1, L.ptr(x), st))
+        ref = torch.relu(F.conv2d(x.permute(0, 3, 1, 2), w, b)).permute(0, 2, 3, 1)
+        err = (y[ri].float() - ref).abs()
+        assert bool((err <= 2e-3 * ref.abs() + 2e-3).all()), (n, float(err.max()))
+        assert not bool((y == 9.0).all(dim=-1).any())            # every pixel of every row was written
+        del y
 
 
 @pytest.fixture(params=[0, 1], ids=["k_conv8w", "k_conv4w"])
