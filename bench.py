@@ -62,6 +62,10 @@ def parse():
     ap.add_argument("--steady-moves", type=int, default=5, help="num_moves cap of the steady-state games (short, so slots turn over)")
     ap.add_argument("--steady-generations", type=int, default=2, help="games per slot in the steady-state leg")
     ap.add_argument("--writer-processes", type=int, default=0, help="steady-state leg: conf['WRITER_PROCESSES'] (0 = writer threads)")
+    ap.add_argument("--graph", type=int, default=0, help="1: every round is one captured launch chain (hipGraph): stem -> tower -> heads -> "
+                    "k_search -> k_compact -> board_advance; no per-launch event timing in this mode")
+    ap.add_argument("--halves", type=int, default=1, choices=[1, 2], help="2: the games run as two half-populations alternating on two "
+                    "streams (engine.DualEngine; implies --graph 1)")
     ap.add_argument("--avg8-leg", type=int, default=1, help="headline configuration only: one warm-up + one step with 8-fold symmetry "
                     "averaging (BASELINE config 3 as written), reported as config3_avg8")
     ap.add_argument("--cpu-baseline", type=int, default=1)
@@ -323,7 +327,7 @@ def run_rank(args):
     rank, world, local = init_from_env(args.backend)
     if local is None:
         raise SystemExit("bench.py: no HIP device visible; the hot path has no CPU fallback")
-    from sejonggo_amd.engine import SelfPlayEngine
+    from sejonggo_amd.engine import SelfPlayEngine, DualEngine
     from sejonggo_amd.net import build_net, build_fused_net
     from sejonggo_amd.stub_nets import make_stub
     from sejonggo_amd.distributed import tuple_dtype, TupleGather, device_identities
@@ -344,8 +348,12 @@ def run_rank(args):
     bcast = broadcast_net(net) if args.net == "resnet" else None
     if bcast is not None and not bcast["identical"]:
         raise SystemExit("bench.py: weight replicas differ after the broadcast")
-    eng = SelfPlayEngine(net, size=S, n_games=G, sims=sims, energy=E, stop_exploration=30, symmetry=args.symmetry,
-                         device=local, seed=1234 + rank)
+    if args.halves == 2:
+        eng = DualEngine(net, n_games=G, size=S, sims=sims, energy=E, stop_exploration=30, symmetry=args.symmetry, device=local,
+                         seed=1234 + rank)
+    else:
+        eng = SelfPlayEngine(net, size=S, n_games=G, sims=sims, energy=E, stop_exploration=30, symmetry=args.symmetry,
+                             device=local, seed=1234 + rank, graph=bool(args.graph))
     eng.start_games(np.arange(G))
     tdt = tuple_dtype(S)
     exchange = TupleGather(tdt)          # side stream, per-batch staging: step k's gather overlaps the search of steps k+1, k+2
@@ -380,7 +388,8 @@ def run_rank(args):
     for _ in range(args.warmup):
         one_step()
     eng.advance_timing()
-    time_convs = args.net == "resnet" and not args.plain_net and hasattr(net, "conv_events")
+    captured = bool(getattr(eng, "graph", False))      # launches inside a graph carry no event timestamps
+    time_convs = args.net == "resnet" and not args.plain_net and hasattr(net, "conv_events") and not captured
     if time_convs:
         net.conv_events = []
         net.side_flops = 0.0
@@ -439,6 +448,8 @@ def run_rank(args):
                        "sharding": "games g -> rank g mod N; weights broadcast from rank 0; %s gather of per-step records to rank 0"
                                    % ("RCCL" if args.backend == "nccl" else "gloo"),
                        "backend": args.backend, "weights_broadcast": bcast},
+            "engine": {"halves": args.halves, "captured_rounds": captured, "packed_input": bool(getattr(eng, "packed", False)),
+                       "graph_replays": (sum(e.n_graph_replays for e in eng.halves) if args.halves == 2 else getattr(eng, "n_graph_replays", 0))},
             "rccl": dict(rccl, tuples_on_rank0=gathered[0],
                          gather="TupleGather: counts all_gather + padded gather to rank 0, 3-stage pipeline on a side stream"),
             "roofline_board_advance": {"bound": "hbm", "kernel": "board_advance in situ (make_play + legal set + history move of the step's leaf list; "

@@ -37,6 +37,8 @@ conf = {
     'GAMES_PER_GPU': 1024,       # concurrent game slots resident on one MI355X
     'NET_DTYPE': 'fp16',
     'SYMMETRY_MODE': 'random1',  # 'random1' = reference behaviour (symmetry.py:127-132); 'avg8' = 8-fold averaging
+    'ENGINE_HALVES': 1,          # 2: two half-populations alternating on two HIP streams (engine.DualEngine), captured rounds
+    'ENGINE_GRAPH': False,       # every engine round one captured launch chain (hipGraph): for launch-bound configurations
     'BLOCKS_PER_GAME': 0,        # tree blocks per resident game; 0 = the engine's default (20 * sims + 128, memory permitting)
     'WRITER_THREADS': 2,         # sample-file writer threads per self-play worker (off the stepping thread)
     'WRITER_PROCESSES': 0,       # > 0: that many torch-free writer PROCESSES instead (own libhdf5 each; for small boards)

@@ -59,7 +59,7 @@ class SelfPlayEngine(object):
     def __init__(self, net, size=None, n_games=None, sims=None, energy=None, stop_exploration=None, num_moves=None,
                  komi=None, self_play=True, dirichlet_alpha=None, dirichlet_epsilon=None, blocks_per_game=0,
                  device=0, symmetry="random1", layout="nhwc", dtype="fp16", seed=0, raise_on_error=True, packed=True,
-                 net2=None):
+                 net2=None, graph=False, stream=None):
         """net2: a second net turns the slots into two-model EVALUATION games (evaluate_worker.py:137: model1 = `net`,
         model2 = `net2`, one tree per player, no Dirichlet noise); start them with start_eval_games."""
         import torch
@@ -123,6 +123,15 @@ class SelfPlayEngine(object):
         self.n_model_positions = [0, 0]    # two-model games: positions evaluated by model1 / model2
         self._primed = False
         self.raise_on_error = raise_on_error   # False: a failing slot (e.g. block pool exhausted) is left to the caller
+        # Captured rounds (hipGraph): one replay = stem from the listed records -> tower -> heads -> k_search -> k_compact ->
+        # board_advance -> status copy, with no host launch in between; graphs are captured lazily per padded batch size and
+        # share one memory pool.  Needs the packed route, one model and one forward pass per list.
+        self.graph = bool(graph) and self.packed and not self.two_model and symmetry != "avg8"
+        self.stream = stream               # a torch stream of this engine's own (DualEngine); None = the caller's current stream
+        self._graphs, self._graph_pool = {}, None
+        self._pol_static = self._val_static = self._kdev = None
+        self._in_flight = False
+        self.n_graph_replays = 0
 
     def close(self):
         if getattr(self, "ctx", None):
@@ -154,8 +163,9 @@ class SelfPlayEngine(object):
         if resign is not None:
             # `if resign and value <= resign` (nomodel_self_play.py:171): None AND 0.0 mean "never resign"
             res = np.array([np.nan if not r else r for r in resign], dtype=np.float32)
-        _lib.check(self.lib.sgo_start_games(self.ctx, C.c_int(n), _lib.ptr(slots), _lib.ptr(noises), _lib.ptr(uniforms),
-                                            C.c_int(uniforms.shape[1]), _lib.ptr(res), _lib.stream_ptr()), "sgo_start_games")
+        with self._on_stream():
+            _lib.check(self.lib.sgo_start_games(self.ctx, C.c_int(n), _lib.ptr(slots), _lib.ptr(noises), _lib.ptr(uniforms),
+                                                C.c_int(uniforms.shape[1]), _lib.ptr(res), _lib.stream_ptr()), "sgo_start_games")
         for i, s in enumerate(slots):
             self.records[int(s)] = []
             self.game_ids[int(s)] = None if ids is None else ids[i]
@@ -181,8 +191,9 @@ class SelfPlayEngine(object):
             return np.array([np.nan if not v else v for v in (r if np.ndim(r) else [r] * n)], dtype=np.float32)
 
         r1, r2 = thr(resign_model1), thr(resign_model2)
-        _lib.check(self.lib.sgo_start_games2(self.ctx, C.c_int(n), _lib.ptr(slots), _lib.ptr(uniforms), C.c_int(uniforms.shape[1]),
-                                             _lib.ptr(r1), _lib.ptr(r2), _lib.ptr(first_model), _lib.stream_ptr()), "sgo_start_games2")
+        with self._on_stream():
+            _lib.check(self.lib.sgo_start_games2(self.ctx, C.c_int(n), _lib.ptr(slots), _lib.ptr(uniforms), C.c_int(uniforms.shape[1]),
+                                                 _lib.ptr(r1), _lib.ptr(r2), _lib.ptr(first_model), _lib.stream_ptr()), "sgo_start_games2")
         for i, s in enumerate(slots):
             self.records[int(s)] = []
             self.game_ids[int(s)] = None if ids is None else ids[i]
@@ -255,8 +266,81 @@ class SelfPlayEngine(object):
             val.index_copy_(0, it, v.to(torch.float32).reshape(-1))
         return pol, val
 
+    def _on_stream(self):
+        import contextlib
+        return self.torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
+
+    def _bucket(self, n):
+        """Batch sizes the captured rounds exist for: n rounded up to 1/32 of the largest list (rows beyond n are evaluated on
+        stale list entries and ignored by k_search: at most 3 % wasted network work, and lockstep games hit G and G * E exactly)."""
+        full = self.G * self.E
+        q = max(64, full // 32)
+        return min(full, -(-n // q) * q)
+
+    def _capture(self, nb):
+        torch = self.torch
+        if self._kdev is None:
+            self._kdev = torch.zeros(1, dtype=torch.int32, device=self.device)
+            self._pol_static = torch.zeros((self.G * self.E, self.A), dtype=torch.float32, device=self.device)
+            self._val_static = torch.zeros((self.G * self.E,), dtype=torch.float32, device=self.device)
+            self._graph_pool = torch.cuda.graph_pool_handle()
+            self._cap_stream = torch.cuda.Stream(device=self.device)
+        kd = self._kdev.data_ptr()
+        # library handles / workspaces of this batch size come into being outside the capture
+        self.net.predict_packed(self._rec_ptr, self._idx_ptr, nb, 0, kd)
+        torch.cuda.current_stream().synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=self._graph_pool, stream=self._cap_stream):
+            p, v = self.net.predict_packed(self._rec_ptr, self._idx_ptr, nb, 0, kd)
+            self._pol_static[:nb].copy_(p)
+            self._val_static[:nb].copy_(v.reshape(nb))
+            _lib.check(self.lib.sgo_step_enqueue(self.ctx, self._pol_static.data_ptr(), self._val_static.data_ptr(), kd,
+                                                 _lib.stream_ptr()), "sgo_step_enqueue")
+        self._graphs[nb] = g
+        return g
+
+    def launch(self):
+        """First half of a step: queue the evaluation of the listed positions and the engine step that consumes it, without
+        waiting (captured-round mode); in the other modes the whole step runs here.  finish() completes it."""
+        n = self.status.n_eval if self._primed else 0
+        if not (self.graph and n > 0):
+            self._step_eager()
+            self._in_flight = False
+            return
+        with self._on_stream():
+            nb = self._bucket(n)
+            g = self._graphs.get(nb) or self._capture(nb)
+            self._kdev.fill_(self._draw_k())       # one symmetry per list (symmetry.py:127-132), read by the stem and by k_search
+            self.n_net_calls += 1
+            self.n_net_positions += n
+            g.replay()
+            self.n_graph_replays += 1
+        self._in_flight = True
+
+    def finish(self):
+        """Second half: wait for the queued round, read what it reported."""
+        if self._in_flight:
+            (self.stream or self.torch.cuda.current_stream()).synchronize()
+            _lib.check(self.lib.sgo_step_status(self.ctx, C.byref(self.status)), "sgo_step_status")
+            self._in_flight = False
+            self.n_steps += 1
+        if self.status.error and self.raise_on_error:
+            raise _lib.SgoError("game slot %d failed with error %d (%s)" % (
+                self.status.error_game, self.status.error,
+                {-201: "tree-block pool exhausted: raise blocks_per_game", -202: "ran out of injected random draws",
+                 -203: "engine state error"}.get(self.status.error, "?")))
+        return self.status
+
     def step(self):
         """One engine step; returns the status struct."""
+        self.launch()
+        return self.finish()
+
+    def _step_eager(self):
+        with self._on_stream():
+            self._step_eager_body()
+
+    def _step_eager_body(self):
         torch = self.torch
         n = self.status.n_eval if self._primed else 0
         if n > 0:
@@ -283,12 +367,6 @@ class SelfPlayEngine(object):
         _lib.check(self.lib.sgo_step(self.ctx, pp, vp, C.c_int(k_used), _lib.stream_ptr(), C.byref(self.status)), "sgo_step")
         self._primed = True
         self.n_steps += 1
-        if self.status.error and self.raise_on_error:
-            raise _lib.SgoError("game slot %d failed with error %d (%s)" % (
-                self.status.error_game, self.status.error,
-                {-201: "tree-block pool exhausted: raise blocks_per_game", -202: "ran out of injected random draws",
-                 -203: "engine state error"}.get(self.status.error, "?")))
-        return self.status
 
     # ------------------------------------------------------------------ records / results
     def drain(self):
@@ -449,3 +527,183 @@ class SelfPlayEngine(object):
         ms, n, p = C.c_double(0), C.c_int64(0), C.c_int64(0)
         _lib.check(self.lib.sgo_advance_timing(self.ctx, C.byref(ms), C.byref(n), C.byref(p)), "sgo_advance_timing")
         return ms.value, n.value, p.value
+
+
+class _SumStatus(object):
+    """The status of a DualEngine step: counts summed over the halves, the first error with its slot in the whole population."""
+    __slots__ = ("n_eval", "n_records", "n_active", "n_done", "error", "error_game", "total_moves", "total_evals", "none_events")
+
+    def __init__(self):
+        for k in self.__slots__:
+            setattr(self, k, 0)
+
+
+class DualEngine(object):
+    """The resident games as TWO half-populations on two HIP streams, alternating (ping-pong): while the MFMA-bound tower of
+    one half's evaluation list runs, the other half's k_search / k_compact / board_advance (one wavefront per game, latency- and
+    HBM-bound) run beside it on the idle VALU side, and the host prepares one half while the GPU works on the other.  Each half
+    is a SelfPlayEngine with captured rounds, so the host issues one graph launch per half and round.  Games are independent
+    state machines: a game's moves, trees and records are what the single-context engine produces for the same draws.
+    Same surface as SelfPlayEngine for the drivers (start_games / step / drain / results / game_data / records / status)."""
+
+    def __init__(self, net, n_games=None, seed=0, device=0, **kw):
+        import torch
+        G = n_games or conf['GAMES_PER_GPU']
+        if G < 2:
+            raise ValueError("DualEngine needs at least two games")
+        kw.pop("stream", None)
+        kw.setdefault("graph", True)
+        sizes = [G - G // 2, G // 2]
+        torch.cuda.set_device(torch.device("cuda", device))
+        self.halves = [SelfPlayEngine(net, n_games=sizes[i], seed=seed + 7919 * i, device=device,
+                                      stream=torch.cuda.Stream(device=torch.device("cuda", device)), **kw) for i in range(2)]
+        self.offsets = [0, sizes[0]]
+        self.G, self.S, self.A, self.E = G, self.halves[0].S, self.halves[0].A, self.halves[0].E
+        self.sims, self.max_moves, self.net = self.halves[0].sims, self.halves[0].max_moves, net
+        self.packed, self.graph, self.two_model = self.halves[0].packed, self.halves[0].graph, False
+        self.status = _SumStatus()
+        self.records = _RecordView(self)
+        self._started = False
+
+    # -- slots -----------------------------------------------------------------------------------------------------
+    def _split(self, slots):
+        slots = np.ascontiguousarray(slots, dtype=np.int64)
+        which = (slots >= self.offsets[1]).astype(np.int64)
+        return [(np.flatnonzero(which == h), slots[which == h] - self.offsets[h]) for h in range(2)]
+
+    def start_games(self, slots, noises=None, uniforms=None, resign=None, ids=None):
+        for h, (pos, local) in enumerate(self._split(slots)):
+            if len(local) == 0:
+                continue
+            pick = lambda a: None if a is None else [a[int(i)] for i in pos]
+            self.halves[h].start_games(local, noises=None if noises is None else np.asarray(noises)[pos],
+                                       uniforms=None if uniforms is None else np.asarray(uniforms)[pos],
+                                       resign=pick(resign), ids=pick(ids))
+
+    def _half_of(self, slot):
+        h = 1 if slot >= self.offsets[1] else 0
+        return self.halves[h], int(slot) - self.offsets[h]
+
+    # -- stepping --------------------------------------------------------------------------------------------------
+    def step(self):
+        """Every half advances one round.  Order per half: finish the round queued by the previous call, queue the next one --
+        so while the host handles one half, the other half's round is running, and both rounds overlap on the GPU."""
+        if not self._started:
+            for e in self.halves:
+                e.launch()
+            self._started = True
+        for e in self.halves:
+            e.finish()
+            e.launch()
+        return self._sum_status()
+
+    def sync(self):
+        """Complete the rounds in flight (before reading records / results of a population that is about to be inspected)."""
+        for e in self.halves:
+            e.finish()
+        self._started = False
+        return self._sum_status()
+
+    def _sum_status(self):
+        st = self.status
+        for k in ("n_eval", "n_records", "n_active", "n_done", "total_moves", "total_evals", "none_events"):
+            setattr(st, k, sum(int(getattr(e.status, k)) for e in self.halves))
+        st.error, st.error_game = 0, 0
+        for h, e in enumerate(self.halves):
+            if e.status.error and not st.error:
+                st.error, st.error_game = int(e.status.error), int(e.status.error_game) + self.offsets[h]
+        return st
+
+    # -- records / results -----------------------------------------------------------------------------------------
+    def drain(self):
+        self.sync()
+        return sum(e.drain() for e in self.halves)
+
+    def results(self, slots=None):
+        self.sync()
+        if slots is None:
+            return np.concatenate([e.results() for e in self.halves])
+        slots = np.ascontiguousarray(slots, dtype=np.int64)
+        out = np.zeros(len(slots), dtype=_lib.GAME_RESULT_DTYPE)
+        for h, (pos, local) in enumerate(self._split(slots)):
+            if len(local):
+                out[pos] = self.halves[h].results(local)
+        return out
+
+    def game_data(self, slot, result, model_name=None):
+        e, local = self._half_of(slot)
+        gd = e.game_data(local, result, model_name)
+        gd['slot'] = int(slot)
+        return gd
+
+    def run(self, max_steps=None):
+        steps = 0
+        while True:
+            st = self.step()
+            steps += 1
+            if st.n_records >= self.G:
+                self.drain()
+            if st.n_active == 0 or (max_steps is not None and steps >= max_steps):
+                break
+        self.drain()
+        res = self.results()
+        return [self.game_data(s, res[s]) for s in range(self.G) if res[s]["done"] == 1]
+
+    def root_table(self, slot):
+        e, local = self._half_of(slot)
+        return e.root_table(local)
+
+    def tree_serialize(self, slot):
+        e, local = self._half_of(slot)
+        return e.tree_serialize(local)
+
+    def board(self, slot):
+        e, local = self._half_of(slot)
+        return e.board(local)
+
+    def advance_timing(self):
+        t = [e.advance_timing() for e in self.halves]
+        return tuple(sum(x[i] for x in t) for i in range(3))
+
+    @property
+    def n_net_calls(self):
+        return sum(e.n_net_calls for e in self.halves)
+
+    @property
+    def n_net_positions(self):
+        return sum(e.n_net_positions for e in self.halves)
+
+    @property
+    def n_steps(self):
+        return sum(e.n_steps for e in self.halves)
+
+    def close(self):
+        for e in self.halves:
+            e.close()
+
+
+class _RecordView(object):
+    """engine.records of a DualEngine: slot -> move list, over the halves' own dicts."""
+
+    def __init__(self, dual):
+        self.dual = dual
+
+    def _loc(self, slot):
+        e, local = self.dual._half_of(slot)
+        return e.records, local
+
+    def __getitem__(self, slot):
+        d, k = self._loc(slot)
+        return d[k]
+
+    def __setitem__(self, slot, value):
+        d, k = self._loc(slot)
+        d[k] = value
+
+    def get(self, slot, default=None):
+        d, k = self._loc(slot)
+        return d.get(k, default)
+
+    def setdefault(self, slot, default):
+        d, k = self._loc(slot)
+        return d.setdefault(k, default)

@@ -105,7 +105,14 @@ def run_selfplay(gpu_id, model_indicator="BEST_SYM", n_games=None, games_per_gpu
               stop_exploration=conf['STOP_EXPLORATION'], komi=conf['KOMI'], self_play=True, symmetry=sym,
               device=gpu_id, seed=gpu_id, raise_on_error=False, blocks_per_game=int(conf.get('BLOCKS_PER_GAME', 0) or 0))
     kw.update(engine_kwargs or {})
-    eng = SelfPlayEngine(net, **kw)
+    # conf['ENGINE_HALVES'] = 2: two half-populations alternating on two streams, every round a captured launch chain
+    # (engine.DualEngine); conf['ENGINE_GRAPH']: captured rounds on one population.  Both pay on small boards / shallow nets,
+    # where a round is launch-bound; at 19x19 with the 20-block net a round is one 85-ms tower and neither matters.
+    if int(conf.get('ENGINE_HALVES', 1) or 1) == 2 and kw['n_games'] >= 2:
+        from .engine import DualEngine
+        eng = DualEngine(net, **kw)
+    else:
+        eng = SelfPlayEngine(net, graph=bool(conf.get('ENGINE_GRAPH', False)), **kw)
     slot_game, slot_resign = {}, {}
     t = {"step": 0.0, "turnover": 0.0, "writer_wait": 0.0, "steps": 0, "moves": 0, "games": 0, "files": 0}
     # Finished games leave the stepping thread at once.  Default: conf['WRITER_THREADS'] threads of this process (libhdf5

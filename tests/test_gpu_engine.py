@@ -363,30 +363,35 @@ class _PackedProbe(object):
         self._lib.check(self.lib.sgo_stem_packed_dev(S, n, records_ptr, index_ptr, int(k), k_dev_ptr, self.w10.data_ptr(),
                                                      self.bias.data_ptr(), self.wcol.data_ptr(), y.data_ptr(),
                                                      torch.cuda.current_stream().cuda_stream), "sgo_stem_packed_dev")
-        assert float(y[..., 145:].abs().max()) == 0.0
+        capturing = torch.cuda.is_current_stream_capturing()      # captured rounds: no host read-backs inside the graph
+        if not capturing:
+            assert float(y[..., 145:].abs().max()) == 0.0
         g = y[:, self.oy, self.ox, :]                                                  # [n, S, S, 256]
         ch = (self.tap[..., None] * 16 + torch.arange(16, device="cuda"))[None].expand(n, S, S, 16)
         planes = torch.gather(g, 3, ch)
         col = (2.0 * y[:, 0, 0, 144] - 1.0)[:, None, None, None].expand(n, S, S, 1)
         X = torch.cat([planes, col.to(planes.dtype)], dim=3)
-        assert bool(((X[..., :16] == 0) | (X[..., :16] == 1)).all())
+        if not capturing:
+            assert bool(((X[..., :16] == 0) | (X[..., :16] == 1)).all())
         return self.net.predict_on_batch(X)
 
     def predict_on_batch(self, X):
         raise AssertionError("the engine must take the packed-record route for this net")
 
 
+@pytest.mark.parametrize("graph", [False, True], ids=["eager", "captured_rounds"])
 @pytest.mark.parametrize("fn", ["async_02.npz", "async_05.npz", "async_07.npz", "async_08.npz"])
-def test_packed_record_route_reproduces_the_golden_games(L, fn):
+def test_packed_record_route_reproduces_the_golden_games(L, fn, graph):
     """The engine's packed-record route (evaluation list of record indices -> sgo_stem_packed_dev, no input tensor) against the
     reference's goldens: 9x9 and 5x5 games incl. the 'No best leaf' path, 19x19 at 400 sims and at 1 600 sims / 32-leaf rounds."""
     from sejonggo_amd.stub_nets import make_stub
     z = load(fn)
     S = int(z["size"])
     net = _PackedProbe(make_stub(bytes(z["net"]).decode(), S), S)
-    eng = _engine(z, net)
-    assert eng.packed and eng.nn_in is None
+    eng = _engine(z, net, graph=graph)
+    assert eng.packed and eng.nn_in is None and eng.graph == graph
     games = eng.run()
+    assert (eng.n_graph_replays > 0) == graph
     gd = games[0]
     assert len(gd["moves"]) == len(z["move_index"])
     for i, mv in enumerate(gd["moves"]):
@@ -397,10 +402,67 @@ def test_packed_record_route_reproduces_the_golden_games(L, fn):
     assert eng.status.total_evals == int(z["n_predict"]) and eng.status.none_events == int(z["none_events"])
     eng.close()
     k = len(z["move_index"]) - 1
-    eng = _engine(z, net, halt_at=k)
+    eng = _engine(z, net, halt_at=k, graph=graph)
     eng.run()
     buf, nn, ne = eng.tree_serialize(0)
     assert nn == z["pm_n_nodes"][k] and hashlib.sha1(buf.tobytes()).digest()[:16] == z["pm_tree_hash"][k].tobytes()
+    eng.close()
+
+
+def test_two_half_populations_on_two_streams_equal_the_oracle(L):
+    """engine.DualEngine: 48 games as two half-populations alternating on two HIP streams, every round a captured launch
+    chain (stem from the records -> ... -> k_search -> k_compact -> board_advance), different round counts per game (some
+    resign, some pass out), slots restarted mid-run.  Each game must equal the oracle's game for the same draws, move for
+    move and tree for tree -- games do not interact, whatever the interleaving of the halves."""
+    from oracle import oracle as ora
+    from sejonggo_amd.engine import DualEngine
+    from sejonggo_amd.stub_nets import make_stub
+    S, sims, E, G, nm = 9, 48, 8, 48, 12
+    net = make_stub("hash", S)
+    rng = np.random.RandomState(31)
+    noises = rng.dirichlet([0.03] * (S * S + 1), size=2 * G)
+    uni = rng.random_sample((2 * G, nm))
+    resign = [None if rng.rand() < 0.6 else float(rng.uniform(-1, 0.2)) for _ in range(2 * G)]
+    eng = DualEngine(_PackedProbe(net, S), n_games=G, size=S, sims=sims, energy=E, stop_exploration=5, num_moves=nm, komi=5.5,
+                     symmetry="identity")
+    assert eng.graph and eng.packed and len(eng.halves) == 2 and eng.halves[0].stream is not eng.halves[1].stream
+    eng.start_games(np.arange(G), noises=noises[:G], uniforms=uni[:G], resign=resign[:G], ids=list(range(G)))
+    done = {}
+    slot_draw = {s: s for s in range(G)}
+    nxt = G
+    for _ in range(4000):
+        st = eng.step()
+        if st.n_done > 0:
+            eng.drain()
+            res = eng.results()
+            restart = []
+            for s in range(G):
+                if res[s]["done"] == 1 and s in slot_draw:
+                    done[slot_draw.pop(s)] = (eng.game_data(s, res[s]), res[s].copy(), eng.tree_serialize(s)[0].tobytes())
+                    eng.records[s] = []
+                    if nxt < 2 * G and s % 3 == 0:          # a third of the slots plays a second game
+                        restart.append(s)
+            if restart:
+                draws = list(range(nxt, nxt + len(restart)))
+                draws = [d for d in draws if d < 2 * G]
+                restart = restart[:len(draws)]
+                eng.start_games(restart, noises=noises[draws], uniforms=uni[draws], resign=[resign[d] for d in draws], ids=draws)
+                for s, d in zip(restart, draws):
+                    slot_draw[s] = d
+                nxt += len(draws)
+        if not slot_draw:
+            break
+    assert not slot_draw and len(done) >= G + 8
+    assert all(e.n_graph_replays > 20 for e in eng.halves)
+    for d, (gd, r, tree) in done.items():
+        g = ora.Game(S, sims, E, 5, nm, uniforms=uni[d], noises=noises[d:d + 1], resign=resign[d]).run(net)
+        o = g.result()
+        assert g.n_moves == len(gd["moves"]) == r["n_moves"] and o["end_reason"] == r["end_reason"] and o["winner"] == r["winner"], d
+        for i, mv in enumerate(gd["moves"]):
+            m = g.move(i)
+            assert np.array_equal(mv["board"], m["board"]) and mv["policy"].tobytes() == m["policy"].tobytes(), (d, i)
+            assert mv["player"] == m["player"] and mv["value"].tobytes() == m["value"].tobytes(), (d, i)
+        assert tree == g.tree_serialize()[0].tobytes(), d
     eng.close()
 
 
@@ -701,8 +763,11 @@ def test_fuzzed_configurations_equal_the_oracle(L, seed):
     noises = rng.dirichlet([0.03] * (S * S + 1), size=G)
     uni = rng.random_sample((G, nm))
     resign = [None if rng.rand() < 0.5 else float(rng.uniform(-1, 1)) for _ in range(G)]
-    eng = SelfPlayEngine(net, size=S, n_games=G, sims=sims, energy=E, stop_exploration=stop, num_moves=nm, komi=komi,
-                         symmetry="identity", self_play=self_play)
+    # odd seeds: board tensors through k_nn_pack, eager steps; even seeds: packed records through the stem kernel, captured rounds
+    route = _PackedProbe(net, S) if seed % 2 == 0 else net
+    eng = SelfPlayEngine(route, size=S, n_games=G, sims=sims, energy=E, stop_exploration=stop, num_moves=nm, komi=komi,
+                         symmetry="identity", self_play=self_play, graph=(seed % 2 == 0))
+    assert eng.graph == (seed % 2 == 0)
     eng.start_games(np.arange(G), noises=noises if self_play else None, uniforms=uni, resign=resign)
     games = {gd["slot"]: gd for gd in eng.run()}
     res = eng.results()
