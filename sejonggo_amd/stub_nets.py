@@ -43,6 +43,15 @@ class _Base(object):
         p, v = self.predict_on_batch(X)
         return p[0], v[0]
 
+    def _on(self, device):
+        """The constant prior vector on `device`, copied there once (a per-call host-to-device copy would also be illegal inside
+        a captured launch chain)."""
+        import torch
+        cache = self.__dict__.setdefault("_dev", {})
+        if device not in cache:
+            cache[device] = torch.from_numpy(self._p).to(device)
+        return cache[device]
+
 
 class UniformNet(_Base):
     def __init__(self, size, name="uniform_stub"):
@@ -54,7 +63,7 @@ class UniformNet(_Base):
         if isinstance(X, np.ndarray):
             return np.tile(self._p, (n, 1)), np.zeros((n, 1), dtype=np.float32)
         import torch
-        p = torch.from_numpy(self._p).to(X.device)
+        p = self._on(X.device)
         return p.unsqueeze(0).repeat(n, 1), torch.zeros((n, 1), dtype=torch.float32, device=X.device)
 
 
@@ -71,7 +80,7 @@ class DummyNet(_Base):
         if isinstance(X, np.ndarray):
             return np.tile(self._p, (n, 1)), np.ones((n, 1), dtype=np.float32)
         import torch
-        p = torch.from_numpy(self._p).to(X.device)
+        p = self._on(X.device)
         return p.unsqueeze(0).repeat(n, 1), torch.ones((n, 1), dtype=torch.float32, device=X.device)
 
 

@@ -911,7 +911,7 @@ def test_stem_packed_kernel(L, S):
     import torch
     import torch.nn.functional as F
     lib = L.load()
-    st = torch.cuda.current_stream().cuda_stream
+    st = L.stream_ptr()
     A, NW, RW = S * S + 1, lib.sgo_plane_words(S), lib.sgo_packed_words(S)
     g = torch.Generator(device="cuda")
     g.manual_seed(100 + S)
@@ -979,7 +979,7 @@ def test_stem_packed_kernel_at_the_headline_batch(L):
     import torch.nn.functional as F
     lib = L.load()
     S, t = 19, 17
-    st = torch.cuda.current_stream().cuda_stream
+    st = L.stream_ptr()
     RW = lib.sgo_packed_words(S)
     torch.manual_seed(2)
     base = 4096
