@@ -360,22 +360,34 @@ def run_rank(args):
     gathered = [0]
     rccl = device_identities()           # which physical device every rank computes on (N ranks must show N distinct devices)
 
+    restarts = [0]
+
     def one_step():
-        """every game advances one move; then this step's records are gathered to rank 0"""
+        """G more positions are produced (every resident game advances one move; a game that ends on the way -- two passes in a
+        row happen with a random-init net on small boards -- is restarted at once, like the worker body does); then this step's
+        records are gathered to rank 0"""
         target = eng.status.total_moves + G
         while eng.status.total_moves < target:
             st = eng.step()
+            if st.error:
+                raise RuntimeError("engine error %d in slot %d" % (st.error, st.error_game))
             if st.n_active < G:
-                raise RuntimeError("a game ended inside the benchmark window")
+                res = eng.results()
+                again = [s for s in range(G) if res[s]["done"] == 1]
+                if again:
+                    eng.drain()
+                    eng.start_games(again)
+                    restarts[0] += len(again)
         n = eng.drain()
-        recs = np.zeros(n, dtype=tdt)
+        recs = np.zeros(n + G, dtype=tdt)
         k = 0
         for s in range(G):
             for mv in eng.records[s]:
-                recs[k]["rank"] = rank; recs[k]["game"] = s; recs[k]["move_n"] = mv["move_n"]
-                recs[k]["player"] = mv["player"]; recs[k]["value"] = mv["value"]; recs[k]["z"] = np.nan
-                recs[k]["pi"] = mv["policy"]; recs[k]["state"] = mv["packed"]; recs[k]["action"] = mv["action"]
-                recs[k]["game_seq"] = mv["game_seq"]
+                r = recs[k]
+                r["rank"] = rank; r["game"] = s; r["move_n"] = mv["move_n"]
+                r["player"] = mv["player"]; r["value"] = mv["value"]; r["z"] = np.nan
+                r["pi"] = mv["policy"]; r["state"] = mv["packed"]; r["action"] = mv["action"]
+                r["game_seq"] = mv["game_seq"]
                 k += 1
             eng.records[s] = []
         for got in exchange.submit(recs[:k]):
@@ -396,6 +408,7 @@ def run_rank(args):
         # launches shorter than ~0.5 ms are sampled (1 in 16): two event calls per launch would make the host the bottleneck
         net.conv_event_stride = 1 if G * E * (S - 2) * (S - 2) >= (1 << 20) else 16
     evals0 = eng.status.total_evals
+    moves0 = eng.status.total_moves
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -409,6 +422,7 @@ def run_rank(args):
     dt = float(tmax.item())
     adv_ms, adv_n, adv_pos = eng.advance_timing()
     evals = eng.status.total_evals - evals0
+    moves = eng.status.total_moves - moves0        # >= G * steps (the last round of a step may carry a few games further)
     conv_ms, conv_fl, conv_n, conv_big_ms, conv_big_n, conv_big_fl = 0.0, 0.0, 0, 0.0, 0, 0.0
     if time_convs:
         evs, net.conv_events = net.conv_events, None
@@ -449,6 +463,7 @@ def run_rank(args):
                                    % ("RCCL" if args.backend == "nccl" else "gloo"),
                        "backend": args.backend, "weights_broadcast": bcast},
             "engine": {"halves": args.halves, "captured_rounds": captured, "packed_input": bool(getattr(eng, "packed", False)),
+                       "positions_in_window": int(moves), "games_restarted_in_window": restarts[0],
                        "graph_replays": (sum(e.n_graph_replays for e in eng.halves) if args.halves == 2 else getattr(eng, "n_graph_replays", 0))},
             "rccl": dict(rccl, tuples_on_rank0=gathered[0],
                          gather="TupleGather: counts all_gather + padded gather to rank 0, 3-stage pipeline on a side stream"),

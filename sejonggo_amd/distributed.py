@@ -180,6 +180,19 @@ class TupleGather(object):
         self.inflight = []          # batches in submit order, each a dict with its stage
         self.n_submitted = 0
         self.bytes_gathered = 0
+        self._pinned = []           # recycled pinned staging blocks (a batch holds its blocks until its copies have run)
+
+    def _host_block(self, nbytes):
+        """A pinned (page-locked) uint8 block of at least nbytes from the recycling list; allocating one costs a system call."""
+        torch = self.torch
+        for i, t in enumerate(self._pinned):
+            if t.numel() >= nbytes:
+                return self._pinned.pop(i)
+        return torch.empty(max(int(nbytes * 1.5), 4096), dtype=torch.uint8, pin_memory=self.on_gpu)
+
+    def _recycle(self, *blocks):
+        self._pinned.extend(b for b in blocks if b is not None)
+        del self._pinned[:-8]
 
     # -- stages ---------------------------------------------------------------------------------------------------
     def _stream(self):
@@ -189,13 +202,14 @@ class TupleGather(object):
     def _stage1(self, tuples):
         torch, dist = self.torch, self.dist
         n = len(tuples)
-        raw = np.frombuffer(np.ascontiguousarray(tuples).tobytes(), dtype=np.uint8)
-        host = torch.empty(max(raw.size, 1), dtype=torch.uint8, pin_memory=self.on_gpu)
-        host[:raw.size].copy_(torch.from_numpy(raw.copy()))
+        raw = np.ascontiguousarray(tuples).view(np.uint8).reshape(-1)
+        host = self._host_block(raw.size)
+        if raw.size:
+            host[:raw.size].copy_(torch.from_numpy(raw))
         b = {"n": n, "nbytes": raw.size, "stage": 1}
         with self._stream():
-            b["payload"] = host.to(self.dev, non_blocking=True) if self.on_gpu else host
-            b["host"] = host                                            # keeps the pinned block alive until the copy has run
+            b["payload"] = host[:max(raw.size, 1)].to(self.dev, non_blocking=True) if self.on_gpu else host[:max(raw.size, 1)].clone()
+            b["host"] = host                                            # the pinned block is recycled once the copy has run (stage 2)
             cnt = torch.tensor([n], dtype=torch.int64).to(self.dev, non_blocking=True)
             b["counts"] = [torch.zeros(1, dtype=torch.int64, device=self.dev) for _ in range(self.world)]
             b["work"] = dist.all_gather(b["counts"], cnt, async_op=True)
@@ -206,7 +220,8 @@ class TupleGather(object):
         torch, dist = self.torch, self.dist
         b["work"].wait()
         with self._stream():
-            counts = [int(c.item()) for c in b["counts"]]                # issued a step ago: no wait worth the name
+            counts = [int(c.item()) for c in b["counts"]]                # issued a step ago: no wait worth the name; orders the payload copy too
+            self._recycle(b.pop("host", None))
             b["count_list"] = counts
             width = max(max(counts), 1) * self.dtype.itemsize
             block = torch.zeros(width, dtype=torch.uint8, device=self.dev)
@@ -230,13 +245,14 @@ class TupleGather(object):
             hosts = []
             for o, c in zip(b["outs"], b["count_list"]):
                 nb = c * self.dtype.itemsize
-                h = torch.empty(max(nb, 1), dtype=torch.uint8, pin_memory=self.on_gpu)
+                h = self._host_block(nb)
                 if nb:
                     h[:nb].copy_(o[:nb], non_blocking=True)
                 hosts.append((h, nb))
             if self.on_gpu:
                 self.side.synchronize()                                  # this batch's own copies; the compute stream is not involved
         parts = [np.frombuffer(h.numpy()[:nb].tobytes(), dtype=self.dtype) for h, nb in hosts]
+        self._recycle(*[h for h, _ in hosts])
         self.bytes_gathered += sum(nb for _, nb in hosts)
         return np.concatenate(parts) if parts else np.zeros(0, dtype=self.dtype)
 

@@ -290,7 +290,9 @@ class SelfPlayEngine(object):
         self.net.predict_packed(self._rec_ptr, self._idx_ptr, nb, 0, kd)
         torch.cuda.current_stream().synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, pool=self._graph_pool, stream=self._cap_stream):
+        # thread_local: other threads of the process (RCCL's watchdog polling its events, writer threads) may keep calling
+        # the runtime while this thread captures
+        with torch.cuda.graph(g, pool=self._graph_pool, stream=self._cap_stream, capture_error_mode="thread_local"):
             p, v = self.net.predict_packed(self._rec_ptr, self._idx_ptr, nb, 0, kd)
             self._pol_static[:nb].copy_(p)
             self._val_static[:nb].copy_(v.reshape(nb))
