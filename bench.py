@@ -66,6 +66,8 @@ def parse():
                     "k_search -> k_compact -> board_advance; no per-launch event timing in this mode")
     ap.add_argument("--halves", type=int, default=1, choices=[1, 2], help="2: the games run as two half-populations alternating on two "
                     "streams (engine.DualEngine; implies --graph 1)")
+    ap.add_argument("--gather-stream", default="side", choices=["side", "step"], help="stream of the tuple gather's copies and collectives")
+    ap.add_argument("--gather", type=int, default=1, help="0: skip the per-step tuple gather (A/B of its cost on small configurations)")
     ap.add_argument("--avg8-leg", type=int, default=1, help="headline configuration only: one warm-up + one step with 8-fold symmetry "
                     "averaging (BASELINE config 3 as written), reported as config3_avg8")
     ap.add_argument("--cpu-baseline", type=int, default=1)
@@ -356,11 +358,12 @@ def run_rank(args):
                              device=local, seed=1234 + rank, graph=bool(args.graph))
     eng.start_games(np.arange(G))
     tdt = tuple_dtype(S)
-    exchange = TupleGather(tdt)          # side stream, per-batch staging: step k's gather overlaps the search of steps k+1, k+2
+    exchange = TupleGather(tdt, side_stream=(args.gather_stream == "side"))          # side stream, per-batch staging: step k's gather overlaps the search of steps k+1, k+2
     gathered = [0]
     rccl = device_identities()           # which physical device every rank computes on (N ranks must show N distinct devices)
 
     restarts = [0]
+    host_s = {"drain": 0.0, "tuples": 0.0, "gather_submit": 0.0}     # host seconds per activity besides stepping (timed region and warm-up)
 
     def one_step():
         """G more positions are produced (every resident game advances one move; a game that ends on the way -- two passes in a
@@ -378,7 +381,9 @@ def run_rank(args):
                     eng.drain()
                     eng.start_games(again)
                     restarts[0] += len(again)
+        h0 = time.perf_counter()
         n = eng.drain()
+        h1 = time.perf_counter()
         recs = np.zeros(n + G, dtype=tdt)
         k = 0
         for s in range(G):
@@ -390,8 +395,12 @@ def run_rank(args):
                 r["game_seq"] = mv["game_seq"]
                 k += 1
             eng.records[s] = []
-        for got in exchange.submit(recs[:k]):
-            gathered[0] += 0 if got is None else len(got)
+        h2 = time.perf_counter()
+        if args.gather:
+            for got in exchange.submit(recs[:k]):
+                gathered[0] += 0 if got is None else len(got)
+        h3 = time.perf_counter()
+        host_s["drain"] += h1 - h0; host_s["tuples"] += h2 - h1; host_s["gather_submit"] += h3 - h2
 
     def sync():
         dist.barrier()
@@ -464,6 +473,7 @@ def run_rank(args):
                        "backend": args.backend, "weights_broadcast": bcast},
             "engine": {"halves": args.halves, "captured_rounds": captured, "packed_input": bool(getattr(eng, "packed", False)),
                        "positions_in_window": int(moves), "games_restarted_in_window": restarts[0],
+                       "host_seconds_outside_stepping_incl_warmup": host_s,
                        "graph_replays": (sum(e.n_graph_replays for e in eng.halves) if args.halves == 2 else getattr(eng, "n_graph_replays", 0))},
             "rccl": dict(rccl, tuples_on_rank0=gathered[0],
                          gather="TupleGather: counts all_gather + padded gather to rank 0, 3-stage pipeline on a side stream"),

@@ -167,7 +167,10 @@ class TupleGather(object):
     On RCCL the gather is 7 concurrent point-to-point transfers into rank 0 over the xGMI mesh; on gloo (CPU tensors) the
     same stages run without a stream.  `submit` returns the batches that completed (possibly none); `flush` drains."""
 
-    def __init__(self, dtype, device=None, dst=0):
+    def __init__(self, dtype, device=None, dst=0, side_stream=True):
+        """side_stream=False queues the copies and collectives on the caller's current (stepping) stream instead: still no host
+        wait on a collective just issued (the three stages stay), but the few microseconds of GPU work sit between two steps
+        rather than beside them -- see DESIGN.md §6 for the measured difference on small configurations."""
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -176,7 +179,7 @@ class TupleGather(object):
         self.world, self.rank = dist.get_world_size(), dist.get_rank()
         self.dev = device if device is not None else _comm_device()
         self.on_gpu = self.dev.type == "cuda"
-        self.side = torch.cuda.Stream(device=self.dev) if self.on_gpu else None
+        self.side = torch.cuda.Stream(device=self.dev) if (self.on_gpu and side_stream) else None
         self.inflight = []          # batches in submit order, each a dict with its stage
         self.n_submitted = 0
         self.bytes_gathered = 0
@@ -197,7 +200,7 @@ class TupleGather(object):
     # -- stages ---------------------------------------------------------------------------------------------------
     def _stream(self):
         import contextlib
-        return self.torch.cuda.stream(self.side) if self.on_gpu else contextlib.nullcontext()
+        return self.torch.cuda.stream(self.side) if self.side is not None else contextlib.nullcontext()
 
     def _stage1(self, tuples):
         torch, dist = self.torch, self.dist
@@ -218,8 +221,8 @@ class TupleGather(object):
 
     def _stage2(self, b):
         torch, dist = self.torch, self.dist
-        b["work"].wait()
         with self._stream():
+            b["work"].wait()                                             # makes the SIDE stream wait; the stepping stream never depends on a collective
             counts = [int(c.item()) for c in b["counts"]]                # issued a step ago: no wait worth the name; orders the payload copy too
             self._recycle(b.pop("host", None))
             b["count_list"] = counts
@@ -237,8 +240,9 @@ class TupleGather(object):
 
     def _stage3(self, b):
         torch = self.torch
-        b["work"].wait()
         b["stage"] = 3
+        with self._stream():
+            b["work"].wait()
         if self.rank != self.dst:
             return None
         with self._stream():
@@ -249,8 +253,10 @@ class TupleGather(object):
                 if nb:
                     h[:nb].copy_(o[:nb], non_blocking=True)
                 hosts.append((h, nb))
-            if self.on_gpu:
+            if self.side is not None:
                 self.side.synchronize()                                  # this batch's own copies; the compute stream is not involved
+            elif self.on_gpu:
+                torch.cuda.current_stream().synchronize()
         parts = [np.frombuffer(h.numpy()[:nb].tobytes(), dtype=self.dtype) for h, nb in hosts]
         self._recycle(*[h for h, _ in hosts])
         self.bytes_gathered += sum(nb for _, nb in hosts)

@@ -385,16 +385,19 @@ class SelfPlayEngine(object):
         self.status.n_records = 0
         if n == 0:
             return 0
-        order = np.lexsort((recs["move_n"][:n], recs["game"][:n]))
+        order = np.lexsort((recs["move_n"][:n], recs["game"][:n])).tolist()
+        # columns as Python lists once (per-element numpy scalar access is the slow part of this loop); the rows of a batch
+        # stay views of ONE copy of its policy / record arrays
+        games, mvn, acts = recs["game"][:n].tolist(), recs["move_n"][:n].tolist(), recs["action"][:n].tolist()
+        players, seqs, vals = recs["player"][:n].tolist(), recs["game_seq"][:n].tolist(), recs["value"][:n].copy()
+        pol, pk = policy[:n].copy(), packed[:n].copy()
+        S = self.S
         for i in order:
-            r = recs[i]
-            a = int(r["action"])
-            y = a // self.S
-            x = a - self.S * y
-            rec = MoveRecord(policy=policy[i].copy(), value=np.float32(r["value"]), move=(x, y), move_n=int(r["move_n"]),
-                             player=int(r["player"]), packed=packed[i].copy(), action=a, game_seq=int(r["game_seq"]))
-            rec.size = self.S
-            self.records.setdefault(int(r["game"]), []).append(rec)
+            a = acts[i]
+            rec = MoveRecord(policy=pol[i], value=vals[i], move=(a % S, a // S), move_n=mvn[i], player=players[i], packed=pk[i],
+                             action=a, game_seq=seqs[i])
+            rec.size = S
+            self.records.setdefault(games[i], []).append(rec)
         return n
 
     def results(self, slots=None):
