@@ -7,7 +7,7 @@ TAG=${1:-r01}
 cd /tmp; export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
-  timeout -k 10 400 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "k_board_advance|k_history_shift|k_advance_planes" --output-format csv -d /tmp/pmc_$c -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-baseline 0 --saturated 0 --steady-state 0 > /tmp/pmc_$c.log 2>&1
+  timeout -k 10 400 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "k_board_advance|k_history_shift|k_advance_planes|k_stem_packed" --output-format csv -d /tmp/pmc_$c -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-baseline 0 --saturated 0 --steady-state 0 --avg8-leg 0 > /tmp/pmc_$c.log 2>&1
   echo "pass $c exit=$?"
 done
 python3 - <<PY

@@ -5,7 +5,7 @@ TAG=${1:-r01}
 shift
 cd /tmp; export TMPDIR=/tmp
 rm -rf /tmp/prof_bench
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -- python3 $R/bench.py --steps 1 --warmup 1 --cpu-baseline 0 --saturated 0 --steady-state 0 "$@" > $R/gpurun_out/prof_${TAG}.log 2>&1
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -- python3 $R/bench.py --steps 1 --warmup 1 --cpu-baseline 0 --saturated 0 --steady-state 0 --avg8-leg 0 "$@" > $R/gpurun_out/prof_${TAG}.log 2>&1
 echo exit=$? >> $R/gpurun_out/prof_${TAG}.log
 cp /tmp/prof_bench/*/*kernel_stats.csv $R/gpurun_out/${TAG}_bench_kernel_stats.csv
 python3 - <<PY
