@@ -167,7 +167,7 @@ typedef struct sgo_config {
     int32_t energy;           /* conf['ENERGY'] (<= 64) */
     int32_t stop_exploration; /* conf['STOP_EXPLORATION'] */
     int32_t num_moves;        /* play_game_async(num_moves); <0 => 2*S*S */
-    int32_t blocks_per_game;  /* tree-block pool per game; <=0 => 20*sims + 128, bounded by the LDS work queue and by 60 % of the free device memory */
+    int32_t blocks_per_game;  /* PRIVATE tree blocks per game; <=0 => 8*sims + 128 (and the default shared pool, below) */
     int32_t self_play;        /* add Dirichlet noise when a tree is created (play.py:400-403) */
     double komi;              /* conf['KOMI'] */
     double dirichlet_epsilon; /* conf['DIRICHLET_EPSILON'] */
@@ -176,6 +176,12 @@ typedef struct sgo_config {
                                  the side not to move follows the move when it holds it (nomodel_self_play.py:203-218);
                                  requires self_play = 0.  Every row of a step's evaluation list belongs to one model:
                                  sgo_eval_models() */
+    int32_t shared_blocks;    /* tree blocks SHARED by all games of the context: a game whose tree outgrows its private blocks
+                                 takes more from here, one at a time, and gives them back when a move prunes its tree.
+                                 > 0: that many; < 0: the default (2*sims per game, at least 12*sims + 128); 0: the default when
+                                 blocks_per_game <= 0, none otherwise (a fixed per-game pool).  All bounded by 60 % of the free
+                                 device memory and, per game, by the id space of k_search's LDS work queue (~38 000 blocks). */
+    int32_t reserved;
 } sgo_config;
 
 typedef struct sgo_status {
@@ -209,12 +215,15 @@ typedef struct sgo_game_result {
     int32_t last_player; /* 'player' when the loop ended (used for "X+R") */
     int32_t done;
     int32_t first_model; /* two_model games: which model moved first = plays black (0 = model1, 1 = model2) */
-    int32_t blocks_high_water; /* most tree blocks of its pool the game ever held at once (of sgo_blocks_per_game) */
+    int32_t blocks_high_water; /* most tree blocks the game ever held at once (private + shared) */
 } sgo_game_result;
 
 sgo_ctx *sgo_ctx_create(const sgo_config *cfg);
 void sgo_ctx_destroy(sgo_ctx *ctx);
-int sgo_blocks_per_game(sgo_ctx *ctx);   /* the per-game tree-block pool this context was created with */
+int sgo_blocks_per_game(sgo_ctx *ctx);   /* the private tree blocks per game this context was created with */
+/* out[0..n): {private blocks per game, local ids per game (private + overflow ids), shared pool blocks, shared blocks free now,
+ * fewest shared blocks ever free, games}.  n <= 6.  Synchronises the device. */
+int sgo_pool_info(sgo_ctx *ctx, int64_t *out, int n);
 /* (Re)start game slots.  noise: [n][A] float64 Dirichlet draws (np.random.dirichlet stand-in, consumed
  * when a tree is created); uniforms: [n][n_uniforms] float64 in [0,1) consumed one per sampled move
  * (np.random.choice stand-in); resign: [n] thresholds, NaN or 0 = None.  HOST pointers; they are copied before the call

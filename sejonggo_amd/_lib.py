@@ -21,7 +21,7 @@ SYMBOLS = [
     "sgo_last_error", "sgo_version", "sgo_device_count", "sgo_set_device", "sgo_plane_words", "sgo_packed_words",
     "sgo_apad", "sgo_game_init", "sgo_make_play", "sgo_take_stones", "sgo_board_query", "sgo_legal_moves", "sgo_get_winner", "sgo_sym_apply",
     "sgo_sym_invert_policy", "sgo_sym_lut", "sgo_pack_dev", "sgo_unpack_dev", "sgo_advance_legal_dev",
-    "sgo_legal_dev", "sgo_score_dev", "sgo_nn_pack_dev", "sgo_bias_act_dev", "sgo_conv3x3_bias_act_dev", "sgo_conv3x3_tower_dev", "sgo_conv3x3_stem_dev", "sgo_conv_tile_order", "sgo_conv_tower_kernel", "sgo_conv_tower_slice_cap", "sgo_advance_mode", "sgo_debug_counters", "sgo_ctx_create", "sgo_ctx_destroy", "sgo_blocks_per_game", "sgo_start_games", "sgo_start_games2", "sgo_eval_models",
+    "sgo_legal_dev", "sgo_score_dev", "sgo_nn_pack_dev", "sgo_bias_act_dev", "sgo_conv3x3_bias_act_dev", "sgo_conv3x3_tower_dev", "sgo_conv3x3_stem_dev", "sgo_conv_tile_order", "sgo_conv_tower_kernel", "sgo_conv_tower_slice_cap", "sgo_advance_mode", "sgo_debug_counters", "sgo_ctx_create", "sgo_ctx_destroy", "sgo_blocks_per_game", "sgo_pool_info", "sgo_start_games", "sgo_start_games2", "sgo_eval_models",
     "sgo_step", "sgo_step_enqueue", "sgo_step_status", "sgo_eval_list", "sgo_stem_packed_dev", "sgo_collect", "sgo_drain_records", "sgo_game_results", "sgo_root_table", "sgo_tree_serialize", "sgo_tree_dump",
     "sgo_game_board", "sgo_set_halt", "sgo_advance_timing",
 ]
@@ -35,7 +35,7 @@ class Config(C.Structure):
     _fields_ = [("size", C.c_int32), ("n_games", C.c_int32), ("sims", C.c_int32), ("energy", C.c_int32),
                 ("stop_exploration", C.c_int32), ("num_moves", C.c_int32), ("blocks_per_game", C.c_int32),
                 ("self_play", C.c_int32), ("komi", C.c_double), ("dirichlet_epsilon", C.c_double),
-                ("device_id", C.c_int32), ("two_model", C.c_int32)]
+                ("device_id", C.c_int32), ("two_model", C.c_int32), ("shared_blocks", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Status(C.Structure):
@@ -97,6 +97,7 @@ def load():
     lib.sgo_step_status.argtypes = [C.c_void_p, C.c_void_p]
     lib.sgo_eval_list.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.sgo_blocks_per_game.argtypes = [C.c_void_p]
+    lib.sgo_pool_info.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     lib.sgo_conv_tile_order.argtypes = [C.c_int]
     lib.sgo_conv_tower_kernel.argtypes = [C.c_int]
     lib.sgo_conv_tower_slice_cap.argtypes = [C.c_long]

@@ -39,7 +39,8 @@ conf = {
     'SYMMETRY_MODE': 'random1',  # 'random1' = reference behaviour (symmetry.py:127-132); 'avg8' = 8-fold averaging
     'ENGINE_HALVES': 1,          # 2: two half-populations alternating on two HIP streams (engine.DualEngine), captured rounds
     'ENGINE_GRAPH': False,       # every engine round one captured launch chain (hipGraph): for launch-bound configurations
-    'BLOCKS_PER_GAME': 0,        # tree blocks per resident game; 0 = the engine's default (20 * sims + 128, memory permitting)
+    'BLOCKS_PER_GAME': 0,        # PRIVATE tree blocks per resident game; 0 = the engine's default (8 * sims + 128)
+    'SHARED_BLOCKS': 0,          # tree blocks shared by all games of a GPU; 0 = default (2 * sims per game) unless BLOCKS_PER_GAME is set, < 0 = default
     'WRITER_THREADS': 2,         # sample-file writer threads per self-play worker (off the stepping thread)
     'WRITER_PROCESSES': 0,       # > 0: that many torch-free writer PROCESSES instead (own libhdf5 each; for small boards)
     'NET_CHANNELS': 256,         # filters of the tower (model.py:58 hard-codes 256)

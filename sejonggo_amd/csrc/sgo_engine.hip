@@ -26,6 +26,7 @@
 // float32; at a root whose priors were mixed with Dirichlet noise priors and score are float64.
 #include <math.h>
 #include <string.h>
+#include <algorithm>
 #include <vector>
 
 #include "sgo_bits.hpp"
@@ -57,7 +58,8 @@ struct GameState {
     float other_value, other_mean;
     float resign2;
     int32_t has_resign2;
-    int32_t min_free, pad_;               // fewest free blocks the pool ever held during this game (high-water mark = cap - min_free)
+    int32_t min_free;                     // fewest free local ids the game ever had (high-water mark = L - min_free)
+    int32_t ovf_hi;                       // overflow local ids [cap, cap + ovf_hi) have been backed at some time in this game
 };
 
 struct Counters {
@@ -75,6 +77,10 @@ struct DevStatus {  // written by k_compact, copied to the host once per step
 struct Ctx {
     sgo_config cfg;
     int S, A, APAD, NW, RW, G, E, cap;
+    // Block ids of a game are LOCAL: [0, cap) live in the game's private region (physical block g * cap + id), [cap, L) are
+    // overflow ids, backed on demand by blocks of a pool SHARED by all games of the context (physical block G * cap + ovfMap).
+    int ovf_cap, L;
+    long pool_blocks;
     int max_moves;       // effective num_moves
     int rec_cap;
     // device arrays
@@ -86,7 +92,11 @@ struct Ctx {
     uint8_t *cBusy;
     int32_t *bParent;     // [G*cap] local parent block (-1 root)
     int32_t *bSlot;       // [G*cap] slot in parent
-    int32_t *freeList;    // [G][cap]
+    int32_t *freeList;    // [G][L] stack of free local ids: the private ones on top, overflow ids (largest first) at the bottom
+    int32_t *ovfMap;      // [G][ovf_cap] shared block behind overflow id cap + j, -1 = not backed
+    int32_t *poolFree;    // [pool_blocks] stack of free shared blocks: popped inside k_search, refilled by k_compact only
+    int32_t *poolRet;     // [pool_blocks] shared blocks released by re-roots / restarts since the last k_compact
+    int32_t *poolCtl;     // [0] top of poolFree, [1] entries of poolRet, [2] low-water mark of [0]
     double *rootP64;      // [G][APAD]
     double *noise;        // [G][APAD]
     double *uniforms;     // [G][max_moves]
@@ -169,9 +179,40 @@ struct Eng {
     size_t gb0;  // g * cap
     __device__ Eng(const Ctx &cc, int gg) : c(cc), g(gg), lane(threadIdx.x & 63), gb0((size_t)gg * cc.cap) {}
 
-    __device__ __forceinline__ size_t slot_base(int blk) const { return (gb0 + blk) * (size_t)G::APAD; }
+    // physical block behind local id `blk` (uniform over the wave): private region, or one dependent load for an overflow id
+    __device__ __forceinline__ size_t ph(int blk) const {
+        if (blk < c.cap) return gb0 + blk;
+        return (size_t)c.G * c.cap + (size_t)c.ovfMap[(size_t)g * c.ovf_cap + (blk - c.cap)];
+    }
+    __device__ __forceinline__ size_t slot_base(int blk) const { return ph(blk) * (size_t)G::APAD; }
     __device__ __forceinline__ bool legal_bit(int blk, int i) const {
-        return (c.legal[(gb0 + blk) * G::NW + (i >> 5)] >> (i & 31)) & 1u;
+        return (c.legal[ph(blk) * G::NW + (i >> 5)] >> (i & 31)) & 1u;
+    }
+    // a block for overflow id `blk` from the shared pool (all lanes call; false = the pool is empty)
+    __device__ bool back(int blk, GameState &st) const {
+        int phys = -1;
+        if (lane == 0) {
+            const int t = atomicSub(&c.poolCtl[0], 1);
+            if (t > 0) {
+                phys = c.poolFree[t - 1];
+                atomicMin(&c.poolCtl[2], t - 1);
+                c.ovfMap[(size_t)g * c.ovf_cap + (blk - c.cap)] = phys;
+            } else {
+                atomicAdd(&c.poolCtl[0], 1);
+            }
+        }
+        phys = __shfl(phys, 0);
+        if (blk - c.cap + 1 > st.ovf_hi) st.ovf_hi = blk - c.cap + 1;
+        return phys >= 0;
+    }
+    // pop a free local id, backed; -1 = out of blocks (private region used up and the shared pool empty, or the id space)
+    __device__ int alloc(GameState &st) const {
+        if (st.free_top <= 0) return -1;
+        const int nb = c.freeList[(size_t)g * c.L + st.free_top - 1];
+        if (nb >= c.cap && !back(nb, st)) return -1;
+        st.free_top--;
+        if (st.free_top < st.min_free) st.min_free = st.free_top;
+        return nb;
     }
 
     // play.py:308-323 on block `blk`; returns chosen slot or -1, and in `child` the chosen slot's child block (-1: a leaf).
@@ -191,7 +232,7 @@ struct Eng {
         for (int j = 0; j < J; j++) {
             const int i = lane + 64 * j;
             const bool in = i < G::APAD;
-            const uint32_t lw = in ? c.legal[(gb0 + blk) * G::NW + (i >> 5)] : 0u;
+            const uint32_t lw = in ? c.legal[sb / G::APAD * G::NW + (i >> 5)] : 0u;
             const int nv = in ? c.cN[sb + i] : 0;
             const int bz = in ? (int)c.cBusy[sb + i] : 1;
             p_[j] = in ? c.cP[sb + i] : 0.f;
@@ -273,9 +314,10 @@ struct Eng {
             int cb = -1;
             int a = top_one(node, st.root_f64 && node == st.root_blk, cb);
             if (a < 0) {
-                int par = c.bParent[gb0 + node];
+                const size_t pn = ph(node);
+                int par = c.bParent[pn];
                 if (par < 0) return false;
-                int ps = c.bSlot[gb0 + node];
+                int ps = c.bSlot[pn];
                 if (lane == (ps & 63)) c.cBusy[slot_base(par) + ps] = 2;
                 node = par;
                 continue;
@@ -336,7 +378,7 @@ struct Eng {
         const size_t fo = (size_t)g * (2 * MAXE) + fi;
         const int pb = c.fParent[fo], slot = c.fSlot[fo], nb = c.fBlk[fo];
         const float vraw = c.fValue[fo];
-        const int leaf_player = white_to_play<S>(c.pos + (gb0 + nb) * G::RW) ? -1 : 1;
+        const int leaf_player = white_to_play<S>(c.pos + ph(nb) * G::RW) ? -1 : 1;
         const float v = (leaf_player == st.original_player) ? vraw : -vraw;
         float leaf_value = 0.f;
         if (lane == (slot & 63)) {
@@ -353,9 +395,11 @@ struct Eng {
         leaf_value = __shfl(leaf_value, slot & 63);
         // Walk to the root.  One memory round trip per level: the next level's parent / slot are requested together with this
         // level's statistics (the walk was three dependent round trips per level: parent, then slot, then N / W).
-        int par = c.bParent[gb0 + pb], ps = c.bSlot[gb0 + pb];
+        const size_t ppb = ph(pb);
+        int par = c.bParent[ppb], ps = c.bSlot[ppb];
         while (par >= 0) {
-            const int npar = c.bParent[gb0 + par], nps = c.bSlot[gb0 + par];
+            const size_t pp = ph(par);
+            const int npar = c.bParent[pp], nps = c.bSlot[pp];
             if (lane == (ps & 63)) {
                 const size_t o = slot_base(par) + ps;
                 int n = c.cN[o] + 1;
@@ -379,10 +423,10 @@ template <int S>
 __global__ __launch_bounds__(64) void k_search(Ctx c, const float *policy, const float *value, int sym_k_imm, const int32_t *sym_k_dev) {
     using G = Geo<S>;
     extern __shared__ int32_t lds[];
-    int32_t *queue = lds;                       // [cap]
-    int32_t *sN = lds + c.cap;                  // [APAD]
+    int32_t *queue = lds;                       // [L]
+    int32_t *sN = lds + c.L;                    // [APAD]
     float *sQ = (float *)(sN + G::APAD);        // [APAD]
-    uint32_t *marks = (uint32_t *)(sQ + G::APAD);  // [(cap+31)/32]
+    uint32_t *marks = (uint32_t *)(sQ + G::APAD);  // [(L+31)/32]
     const int g = blockIdx.x;
     const int lane = threadIdx.x;
     Eng<S> e(c, g);
@@ -401,7 +445,7 @@ __global__ __launch_bounds__(64) void k_search(Ctx c, const float *policy, const
     auto finish = [&](int reason) {
         st.end_reason = reason;
         int bp = 0, wp = 0;
-        if (lane == 0) score_record<S>(c.pos + (e.gb0 + st.root_blk) * G::RW, bp, wp);
+        if (lane == 0) score_record<S>(c.pos + e.ph(st.root_blk) * G::RW, bp, wp);
         bp = __shfl(bp, 0);
         wp = __shfl(wp, 0);
         double white = (double)wp + c.cfg.komi;
@@ -429,7 +473,7 @@ __global__ __launch_bounds__(64) void k_search(Ctx c, const float *policy, const
     if (st.phase == PH_WAIT_ROOT) {
         if (!st.root_requested) {
             st.root_requested = 1;
-            if (lane == 0) c.reqBlk[rbase] = (int32_t)(e.gb0 + st.root_blk);
+            if (lane == 0) c.reqBlk[rbase] = (int32_t)e.ph(st.root_blk);
             st.n_req = 1;
             st.req_kind = 0;
             run = false;
@@ -446,7 +490,7 @@ __global__ __launch_bounds__(64) void k_search(Ctx c, const float *policy, const
                 finish(1);
             } else {
                 // "if not mcts_tree or not mcts_tree['subtree']": the root block carries children iff flag set
-                bool expanded = c.bSlot[e.gb0 + st.root_blk] != -2;  // -2 marks "block holds no children yet"
+                bool expanded = c.bSlot[e.ph(st.root_blk)] != -2;  // -2 marks "block holds no children yet"
                 if (!expanded) {
                     const double *noise = nullptr;
                     if (c.cfg.self_play) {
@@ -456,7 +500,7 @@ __global__ __launch_bounds__(64) void k_search(Ctx c, const float *policy, const
                     }
                     if (run) {
                         e.expand(st.root_blk, prow, lut, noise, c.cfg.dirichlet_epsilon);
-                        if (lane == 0) c.bSlot[e.gb0 + st.root_blk] = -1;
+                        if (lane == 0) c.bSlot[e.ph(st.root_blk)] = -1;
                         st.root_f64 = noise ? 1 : 0;
                         st.root_count = 0;
                         st.root_value = 0.f;
@@ -466,7 +510,7 @@ __global__ __launch_bounds__(64) void k_search(Ctx c, const float *policy, const
                 if (run) {
                     st.rounds_left = c.cfg.sims / c.cfg.energy;
                     st.e_left = -1;
-                    st.original_player = white_to_play<S>(c.pos + (e.gb0 + st.root_blk) * G::RW) ? -1 : 1;
+                    st.original_player = white_to_play<S>(c.pos + e.ph(st.root_blk) * G::RW) ? -1 : 1;
                     st.phase = PH_SEARCH;
                     if (c.cfg.sims < c.cfg.energy) fail(SGO_ERR_STATE);  // zero simulations: the reference cannot pick a move
                 }
@@ -557,7 +601,7 @@ __global__ __launch_bounds__(64) void k_search(Ctx c, const float *policy, const
                 c.recs[ri] = r;
                 atomicAdd(&c.counters->total_moves, 1ull);
             }
-            for (int i = lane; i < G::RW; i += 64) c.recPacked[(size_t)ri * G::RW + i] = c.pos[(e.gb0 + st.root_blk) * G::RW + i];
+            for (int i = lane; i < G::RW; i += 64) c.recPacked[(size_t)ri * G::RW + i] = c.pos[e.ph(st.root_blk) * G::RW + i];
             for (int i = lane; i < G::A; i += 64) {
                 double p = 0;
                 if (e.legal_bit(st.root_blk, i)) p = st.root_f64 ? c.rootP64[(size_t)g * G::APAD + i] : (double)c.cP[sb + i];
@@ -577,12 +621,12 @@ __global__ __launch_bounds__(64) void k_search(Ctx c, const float *policy, const
             st.root_count = __shfl(rc, selected & 63);
             st.root_value = __shfl(rv, selected & 63);
             st.root_mean = __shfl(rm, selected & 63);
-            const int mover = white_to_play<S>(c.pos + (e.gb0 + st.root_blk) * G::RW) ? -1 : 1;
+            const int mover = white_to_play<S>(c.pos + e.ph(st.root_blk) * G::RW) ? -1 : 1;
             // Two-model games (self_play == False, nomodel_self_play.py:203-208): the other player's tree follows the move when
             // it holds it ("if other_mcts and index in other_mcts['subtree']"); a child that was never evaluated there has an
             // empty subtree, i.e. the tree is rebuilt by new_tree() when its owner moves next -- here: no block, onr stays -1.
             int onr = -1;
-            if (c.cfg.two_model && st.other_root >= 0 && c.bSlot[e.gb0 + st.other_root] != -2) {
+            if (c.cfg.two_model && st.other_root >= 0 && c.bSlot[e.ph(st.other_root)] != -2) {
                 const size_t osb = e.slot_base(st.other_root);
                 int ocb = -1, oc = 0; float ov = 0, om = 0;
                 if (lane == (selected & 63) && e.legal_bit(st.other_root, selected)) {
@@ -596,8 +640,8 @@ __global__ __launch_bounds__(64) void k_search(Ctx c, const float *policy, const
             st.root_blk = nr;
             st.root_f64 = 0;
             if (lane == 0) {
-                c.bParent[e.gb0 + nr] = -1; c.bSlot[e.gb0 + nr] = -1;
-                if (onr >= 0) { c.bParent[e.gb0 + onr] = -1; c.bSlot[e.gb0 + onr] = -1; }
+                c.bParent[e.ph(nr)] = -1; c.bSlot[e.ph(nr)] = -1;
+                if (onr >= 0) { c.bParent[e.ph(onr)] = -1; c.bSlot[e.ph(onr)] = -1; }
             }
             // mark: which blocks hang below the new root(s)?  Every allocated block is linked from its parent exactly once (the
             // graft in back_propagate) and carries that parent in bParent, so "reachable from the new root" = "the parent chain
@@ -606,18 +650,26 @@ __global__ __launch_bounds__(64) void k_search(Ctx c, const float *policy, const
             // round trip per CHILD ARRAY of every kept block (22 ms for a late-game tree, measured; now tens of microseconds).
             constexpr int KEEP = -3, DROP = -4;
             int *par = queue;
-            for (int b = lane; b < c.cap; b += 64) {
-                const int pv = c.bParent[e.gb0 + b];
+            // local ids in use or used before: the private region plus the overflow ids backed so far in this game; ids beyond
+            // Lu have never left the bottom of the free stack (entries [0, L - Lu), untouched here)
+            const int Lu = c.cap + st.ovf_hi, base = c.L - Lu;
+            for (int b = lane; b < Lu; b += 64) {
+                int pv = DROP;
+                if (b < c.cap) pv = c.bParent[e.gb0 + b];
+                else {
+                    const int ob = c.ovfMap[(size_t)g * c.ovf_cap + (b - c.cap)];      // -1: not backed = free
+                    if (ob >= 0) pv = c.bParent[(size_t)c.G * c.cap + ob];
+                }
                 par[b] = pv < 0 ? DROP : pv;                       // other roots (the old one): dropped
             }
             __syncthreads();
-            for (int i = lane; i < st.free_top; i += 64) par[c.freeList[(size_t)g * c.cap + i]] = DROP;   // stale parents of free blocks
+            for (int i = base + lane; i < st.free_top; i += 64) par[c.freeList[(size_t)g * c.L + i]] = DROP;   // stale parents of free blocks
             __syncthreads();
             if (lane == 0) { par[nr] = KEEP; if (onr >= 0) par[onr] = KEEP; }
             __syncthreads();
             for (;;) {
                 bool open = false;
-                for (int b = lane; b < c.cap; b += 64) {
+                for (int b = lane; b < Lu; b += 64) {
                     const int pv = par[b];
                     if (pv >= 0) {
                         const int pp = par[pv];                    // KEEP / DROP resolve b; otherwise jump to the grandparent
@@ -628,12 +680,25 @@ __global__ __launch_bounds__(64) void k_search(Ctx c, const float *policy, const
                 __syncthreads();
                 if (!__any(open)) break;
             }
-            int ft = 0;
-            for (int b0 = 0; b0 < c.cap; b0 += 64) {
-                int b = b0 + lane;
-                bool fr = b < c.cap && par[b] != KEEP;
-                unsigned long long m = __ballot(fr);
-                if (fr) c.freeList[(size_t)g * c.cap + ft + __popcll(m & ((1ull << lane) - 1ull))] = b;
+            // rebuild the stack above `base`, ids DESCENDING so that the private ids pop before the overflow ids; an overflow id
+            // that is free now gives its block back to the shared pool (poolRet: merged into poolFree by k_compact, so a pop in
+            // this launch never meets a push)
+            int ft = base;
+            for (int b1 = ((Lu + 63) & ~63); b1 > 0; b1 -= 64) {
+                const int b = b1 - 1 - lane;
+                const bool fr = b < Lu && par[b] != KEEP;
+                const unsigned long long m = __ballot(fr);
+                if (fr) {
+                    c.freeList[(size_t)g * c.L + ft + __popcll(m & ((1ull << lane) - 1ull))] = b;
+                    if (b >= c.cap) {
+                        const size_t mi = (size_t)g * c.ovf_cap + (b - c.cap);
+                        const int ob = c.ovfMap[mi];
+                        if (ob >= 0) {
+                            c.poolRet[atomicAdd(&c.poolCtl[1], 1)] = ob;
+                            c.ovfMap[mi] = -1;
+                        }
+                    }
+                }
                 ft += __popcll(m);
             }
             st.free_top = ft;
@@ -642,13 +707,11 @@ __global__ __launch_bounds__(64) void k_search(Ctx c, const float *policy, const
                 if (onr < 0) {
                     // the other player's tree is empty: a fresh root block holding the position after the move (a copy of the
                     // mover's new root), unexpanded -- new_tree() fills it when that player's root evaluation arrives
-                    if (st.free_top <= 0) { fail(SGO_ERR_CAPACITY); break; }
-                    onr = c.freeList[(size_t)g * c.cap + st.free_top - 1];
-                    st.free_top--;
-                    if (st.free_top < st.min_free) st.min_free = st.free_top;
-                    for (int i = lane; i < G::RW; i += 64) c.pos[(e.gb0 + onr) * G::RW + i] = c.pos[(e.gb0 + nr) * G::RW + i];
-                    for (int i = lane; i < G::NW; i += 64) c.legal[(e.gb0 + onr) * G::NW + i] = c.legal[(e.gb0 + nr) * G::NW + i];
-                    if (lane == 0) { c.bParent[e.gb0 + onr] = -1; c.bSlot[e.gb0 + onr] = -2; }
+                    onr = e.alloc(st);
+                    if (onr < 0) { fail(SGO_ERR_CAPACITY); break; }
+                    for (int i = lane; i < G::RW; i += 64) c.pos[e.ph(onr) * G::RW + i] = c.pos[e.ph(nr) * G::RW + i];
+                    for (int i = lane; i < G::NW; i += 64) c.legal[e.ph(onr) * G::NW + i] = c.legal[e.ph(nr) * G::NW + i];
+                    if (lane == 0) { c.bParent[e.ph(onr)] = -1; c.bSlot[e.ph(onr)] = -2; }
                     st.other_count = 0; st.other_value = 0.f; st.other_mean = 0.f;
                     __syncthreads();
                 }
@@ -666,7 +729,7 @@ __global__ __launch_bounds__(64) void k_search(Ctx c, const float *policy, const
             if (st.move_n == c.cfg.stop_exploration) st.temperature = 0;
             st.phase = PH_WAIT_ROOT;
             st.root_requested = 1;
-            if (lane == 0) c.reqBlk[rbase] = (int32_t)(e.gb0 + st.root_blk);
+            if (lane == 0) c.reqBlk[rbase] = (int32_t)e.ph(st.root_blk);
             st.n_req = 1;
             st.req_kind = 0;
             run = false;
@@ -695,18 +758,16 @@ __global__ __launch_bounds__(64) void k_search(Ctx c, const float *policy, const
                 st.pre_bp++;
                 continue;
             }
-            if (st.free_top <= 0) { fail(SGO_ERR_CAPACITY); break; }
-            const int nb = c.freeList[(size_t)g * c.cap + st.free_top - 1];
-            st.free_top--;
-            if (st.free_top < st.min_free) st.min_free = st.free_top;
+            const int nb = e.alloc(st);
+            if (nb < 0) { fail(SGO_ERR_CAPACITY); break; }
             const size_t fo = fbase + (st.fifo_tail % (2 * MAXE));
             if (lane == 0) {
-                c.bParent[e.gb0 + nb] = pb;
-                c.bSlot[e.gb0 + nb] = slot;
+                c.bParent[e.ph(nb)] = pb;
+                c.bSlot[e.ph(nb)] = slot;
                 c.fParent[fo] = pb; c.fSlot[fo] = slot; c.fBlk[fo] = nb;
                 c.fEvalLocal[fo] = st.n_req; c.fEvaluated[fo] = 0;
-                c.reqBlk[rbase + st.n_req] = (int32_t)(e.gb0 + nb);
-                c.reqParent[rbase + st.n_req] = (int32_t)(e.gb0 + pb);
+                c.reqBlk[rbase + st.n_req] = (int32_t)e.ph(nb);
+                c.reqParent[rbase + st.n_req] = (int32_t)e.ph(pb);
                 c.reqMove[rbase + st.n_req] = slot;
             }
             st.fifo_tail++;
@@ -790,6 +851,14 @@ __global__ __launch_bounds__(1024) void k_compact(Ctx c) {
         if (s.req_kind == 1) bl += s.n_req;
         else br += s.n_req;
     }
+    // shared blocks released during this step's k_search (and by k_start since the previous step) go back on the free stack
+    // here, between two k_search launches: pops and pushes never run concurrently
+    {
+        const int nret = c.poolCtl[1], top = c.poolCtl[0];
+        for (int i = t; i < nret; i += 1024) c.poolFree[top + i] = c.poolRet[i];
+        __syncthreads();
+        if (t == 0 && nret > 0) { c.poolCtl[0] = top + nret; c.poolCtl[1] = 0; }
+    }
     if (t == 1023) {
         DevStatus d;
         d.n_eval = sE[1023]; d.n_leaf = sL[1023]; d.n_records = c.counters->rec_count;
@@ -853,9 +922,19 @@ __global__ __launch_bounds__(64) void k_start(Ctx c, int n, StageLayout L, int h
         }
         c.legal[gb0 * G::NW + i] = w;
     }
-    for (int b = lane; b < c.cap - 1; b += 64) c.freeList[(size_t)g * c.cap + b] = c.cap - 1 - b;  // pops give 1,2,3,...
-    st.free_top = c.cap - 1;
-    st.min_free = c.cap - 1;
+    // whatever the slot's previous game still holds of the shared pool goes back to it
+    for (int j = lane; j < c.ovf_cap; j += 64) {
+        const size_t mi = (size_t)g * c.ovf_cap + j;
+        const int ob = c.ovfMap[mi];
+        if (ob >= 0) {
+            c.poolRet[atomicAdd(&c.poolCtl[1], 1)] = ob;
+            c.ovfMap[mi] = -1;
+        }
+    }
+    for (int b = lane; b < c.L - 1; b += 64) c.freeList[(size_t)g * c.L + b] = c.L - 1 - b;  // pops give 1,2,3,...: private ids first
+    st.free_top = c.L - 1;
+    st.min_free = c.L - 1;
+    st.ovf_hi = 0;
     if (lane == 0) {
         c.bParent[gb0] = -1;
         c.bSlot[gb0] = -2;  // no children yet
@@ -865,7 +944,7 @@ __global__ __launch_bounds__(64) void k_start(Ctx c, int n, StageLayout L, int h
 
 template <int S>
 static size_t search_lds(const Ctx &c) {
-    return sizeof(int32_t) * ((size_t)c.cap + 2 * Geo<S>::APAD + (c.cap + 31) / 32 + 4);
+    return sizeof(int32_t) * ((size_t)c.L + 2 * Geo<S>::APAD + (c.L + 31) / 32 + 4);
 }
 
 }  // namespace sgo
@@ -891,7 +970,7 @@ static int dalloc(T **p, size_t n) {
 }
 
 static int ctx_alloc(Ctx &c) {
-    const size_t nb = (size_t)c.G * c.cap;
+    const size_t nb = (size_t)c.G * c.cap + (size_t)c.pool_blocks;       // private regions, then the shared pool
     CK(dalloc(&c.gs, c.G));
     CK(dalloc(&c.pos, nb * c.RW));
     CK(dalloc(&c.legal, nb * c.NW));
@@ -903,7 +982,19 @@ static int ctx_alloc(Ctx &c) {
     CK(dalloc(&c.cBusy, nb * c.APAD));
     CK(dalloc(&c.bParent, nb));
     CK(dalloc(&c.bSlot, nb));
-    CK(dalloc(&c.freeList, nb));
+    CK(dalloc(&c.freeList, (size_t)c.G * c.L));
+    CK(dalloc(&c.ovfMap, (size_t)c.G * c.ovf_cap));
+    CK(dalloc(&c.poolFree, (size_t)c.pool_blocks));
+    CK(dalloc(&c.poolRet, (size_t)c.pool_blocks));
+    CK(dalloc(&c.poolCtl, 4));
+    if (c.ovf_cap > 0) SGO_HIP(hipMemset(c.ovfMap, 0xff, sizeof(int32_t) * (size_t)c.G * c.ovf_cap));   // -1: not backed
+    {
+        std::vector<int32_t> ids((size_t)c.pool_blocks);
+        for (size_t i = 0; i < ids.size(); i++) ids[i] = (int32_t)(ids.size() - 1 - i);                  // pops give 0, 1, 2, ...
+        if (!ids.empty()) SGO_HIP(hipMemcpy(c.poolFree, ids.data(), sizeof(int32_t) * ids.size(), hipMemcpyHostToDevice));
+        const int32_t ctl[4] = {(int32_t)c.pool_blocks, 0, (int32_t)c.pool_blocks, 0};
+        SGO_HIP(hipMemcpy(c.poolCtl, ctl, sizeof ctl, hipMemcpyHostToDevice));
+    }
     CK(dalloc(&c.rootP64, (size_t)c.G * c.APAD));
     CK(dalloc(&c.noise, (size_t)c.G * c.APAD));
     CK(dalloc(&c.uniforms, (size_t)c.G * (c.max_moves ? c.max_moves : 1)));
@@ -945,7 +1036,7 @@ static int ctx_alloc(Ctx &c) {
 }
 
 static void ctx_free(Ctx &c) {
-    void *ptrs[] = {c.gs, c.pos, c.legal, c.cP, c.cW, c.cQ, c.cN, c.cB, c.cBusy, c.bParent, c.bSlot, c.freeList,
+    void *ptrs[] = {c.gs, c.pos, c.legal, c.cP, c.cW, c.cQ, c.cN, c.cB, c.cBusy, c.bParent, c.bSlot, c.freeList, c.ovfMap, c.poolFree, c.poolRet, c.poolCtl,
                     c.rootP64, c.noise, c.uniforms, c.fParent, c.fSlot, c.fBlk, c.fEvalLocal, c.fEvaluated, c.fValue,
                     c.reqBlk, c.reqParent, c.reqMove, c.evalIdx, c.leafIn, c.leafMv, c.leafOut, c.leafRow, c.evalModel, c.rootIdx, c.rootRow, c.recs, c.recPacked,
                     c.recPolicy, c.counters, c.dstatus, c.symLut, c.stage};
@@ -969,32 +1060,47 @@ sgo_ctx *sgo_ctx_create(const sgo_config *cfg) {
     if (c.cfg.two_model && c.cfg.self_play) { set_error("sgo_ctx_create: two_model games are not self-play games"); delete x; return nullptr; }
     c.S = cfg->size; c.A = c.S * c.S + 1; c.NW = sgo_plane_words(c.S); c.RW = sgo_packed_words(c.S);
     c.APAD = 32 * c.NW; c.G = cfg->n_games; c.E = cfg->energy;
-    if (cfg->blocks_per_game > 0) {
-        c.cap = cfg->blocks_per_game;
-    } else {
-        // Default pool: 20 sims + 128 blocks per game.  A search adds <= sims blocks and a move keeps the chosen child's subtree,
-        // so a tree settles at sims / (1 - f) blocks, f = the share of the visits under the chosen child: late in a game, with
-        // argmax moves, f passes 0.9 -- with 10 sims + 64 (round 1's default) 32 of 256 full-length 19x19 / 400-sim games ran out
-        // of blocks and were discarded, with 20 sims + 128 none (tools/stress_selfplay.py).  Bounded by the k_search work queue in
-        // LDS and by 60 % of the device memory that is free now (BASELINE config 5: 1 024 games x 1 600 sims).
-        long want = 20L * cfg->sims + 128;
-        const long lds_max = (160L * 1024 / 4 - 2L * c.APAD - 4) * 32 / 33 - 32;
-        if (want > lds_max) want = lds_max;
-        const size_t per_block = sizeof(uint32_t) * ((size_t)c.RW + c.NW) + (size_t)c.APAD * (4 * 5 + 1) + 3 * sizeof(int32_t);
+    // Tree blocks.  A search adds <= sims blocks and a move keeps the chosen child's subtree, so a tree settles at sims / (1 - f)
+    // blocks, f = the share of the visits under the chosen child; over 512 full-length 19x19 / 400-sim games (20-block net) the
+    // high-water mark was 4.2 sims in the median, 9.9 sims at the 99th percentile, 12.1 sims at most
+    // (profiles/r03_fullgame_headline.json).  Sizing every game for the worst tree wastes four fifths of the memory (round 2:
+    // 20 sims + 128 per game = 74 GB at 1 024 games) and still loses games where memory forces less (config 5 at 1 024 games:
+    // 11.8 sims).  So: a PRIVATE region per game that covers most games (8 sims + 128), local ids beyond it backed on demand
+    // from a pool SHARED by the context (2 sims per game, at least 12 sims), up to the id space k_search's LDS work queue
+    // allows.  blocks_per_game > 0 fixes the private region; shared_blocks: > 0 fixes the pool, 0 = the default pool when the
+    // private region is the default too and none otherwise (the round-2 behaviour: a fixed per-game pool), < 0 = default pool.
+    const long lds_max = (160L * 1024 / 4 - 2L * c.APAD - 4) * 32 / 33 - 32;
+    const size_t per_block = sizeof(uint32_t) * ((size_t)c.RW + c.NW) + (size_t)c.APAD * (4 * 5 + 1) + 3 * sizeof(int32_t);
+    long priv = cfg->blocks_per_game > 0 ? cfg->blocks_per_game : 8L * cfg->sims + 128;
+    long pool = cfg->shared_blocks > 0 ? cfg->shared_blocks
+                : (cfg->shared_blocks < 0 || cfg->blocks_per_game <= 0) ? std::max(2L * cfg->sims * c.G, 12L * cfg->sims + 128) : 0;
+    if (cfg->blocks_per_game <= 0 && priv > lds_max) priv = lds_max;
+    {
         size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) {
-            const long fit = (long)(free_b / 10 * 6 / ((size_t)c.G * per_block));
-            if (want > fit) want = fit;
+        if ((cfg->blocks_per_game <= 0 || cfg->shared_blocks <= 0) && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) {
+            const double fit = (double)(free_b / 10 * 6) / (double)per_block;        // blocks that fit in 60 % of the free memory
+            const double want = (double)priv * c.G + (double)pool;
+            if (want > fit) {
+                const double r = fit / want;
+                if (cfg->blocks_per_game <= 0) priv = (long)(priv * r);
+                if (cfg->shared_blocks <= 0) pool = (long)(pool * r);
+            }
         }
-        c.cap = (int)want;
     }
-    if (c.cap < cfg->energy + 2) c.cap = cfg->energy + 2;
+    if (priv < cfg->energy + 2) priv = cfg->energy + 2;
+    long L = priv + pool;
+    if (L > 40L * cfg->sims + 256 && cfg->shared_blocks <= 0) L = std::max(priv, 40L * cfg->sims + 256);
+    if (L > lds_max) L = std::max(priv, lds_max);
+    c.cap = (int)priv;
+    c.L = (int)L;
+    c.ovf_cap = (int)(L - priv);
+    c.pool_blocks = c.ovf_cap > 0 ? pool : 0;
     c.max_moves = cfg->num_moves < 0 ? 2 * c.S * c.S : cfg->num_moves;
     c.rec_cap = 2 * c.G + 16;
     c.last_n_eval = 0;
     c.gs = nullptr; c.hstatus = nullptr;
-    // LDS budget of k_search: queue[cap] + sN/sQ + marks
-    size_t lds = sizeof(int32_t) * ((size_t)c.cap + 2 * c.APAD + (c.cap + 31) / 32 + 4);
+    // LDS budget of k_search: queue[L] + sN/sQ + marks
+    size_t lds = sizeof(int32_t) * ((size_t)c.L + 2 * c.APAD + (c.L + 31) / 32 + 4);
     if (lds > 160 * 1024) { set_error("sgo_ctx_create: blocks_per_game too large for the LDS work queue"); delete x; return nullptr; }
     if (ctx_alloc(c) != SGO_OK) { ctx_free(c); delete x; return nullptr; }
     x->h.stage_cap = stage_layout(c.G, c.APAD, c.max_moves, true).total;
@@ -1013,6 +1119,17 @@ sgo_ctx *sgo_ctx_create(const sgo_config *cfg) {
 int sgo_blocks_per_game(sgo_ctx *x) {
     if (!x) { set_error("sgo_blocks_per_game: bad argument"); return SGO_ERR_ARG; }
     return x->c.cap;
+}
+
+int sgo_pool_info(sgo_ctx *x, int64_t *out, int n) {
+    if (!x || !out || n < 0) { set_error("sgo_pool_info: bad argument"); return SGO_ERR_ARG; }
+    Ctx &c = x->c;
+    int32_t ctl[4] = {0, 0, 0, 0};
+    SGO_HIP(hipDeviceSynchronize());
+    SGO_HIP(hipMemcpy(ctl, c.poolCtl, sizeof ctl, hipMemcpyDeviceToHost));
+    const int64_t v[6] = {c.cap, c.L, c.pool_blocks, (int64_t)ctl[0] + ctl[1], ctl[2], c.G};
+    for (int i = 0; i < n && i < 6; i++) out[i] = v[i];
+    return SGO_OK;
 }
 
 void sgo_ctx_destroy(sgo_ctx *x) {
@@ -1216,7 +1333,7 @@ int sgo_game_results(sgo_ctx *x, int n, const int32_t *slots, sgo_game_result *o
         out[i].winner = s.winner; out[i].black = s.black; out[i].white = s.white; out[i].end_reason = s.end_reason;
         out[i].n_moves = s.n_moves; out[i].last_player = s.last_player; out[i].done = (s.phase == PH_DONE) ? 1 : 0;
         out[i].first_model = s.first_model;
-        out[i].blocks_high_water = c.cap - s.min_free;
+        out[i].blocks_high_water = c.L - s.min_free;
         if (s.error) out[i].done = s.error;
     }
     return SGO_OK;
@@ -1241,20 +1358,44 @@ struct Snap {
     std::vector<uint8_t> busy;
     std::vector<uint32_t> legal;
     std::vector<double> p64;
+    std::vector<int32_t> ovf;     // the game's row of the overflow map
 };
+// physical block behind local id `blk` of game g, given the game's row of the overflow map
+static size_t host_phys(const Ctx &c, int g, int blk, const std::vector<int32_t> &ovf) {
+    if (blk < c.cap) return (size_t)g * c.cap + blk;
+    return (size_t)c.G * c.cap + (size_t)ovf[blk - c.cap];
+}
+static int ovf_row(Ctx &c, int g, std::vector<int32_t> &ovf) {
+    ovf.assign((size_t)c.ovf_cap, -1);
+    if (c.ovf_cap > 0)
+        SGO_HIP(hipMemcpy(ovf.data(), c.ovfMap + (size_t)g * c.ovf_cap, sizeof(int32_t) * c.ovf_cap, hipMemcpyDeviceToHost));
+    return SGO_OK;
+}
 static int snapshot(Ctx &c, int g, Snap &sn) {
     SGO_HIP(hipDeviceSynchronize());
     SGO_HIP(hipMemcpy(&sn.s, c.gs + g, sizeof(GameState), hipMemcpyDeviceToHost));
-    const size_t nb = c.cap, ns = nb * c.APAD, off = (size_t)g * c.cap;
+    CK(ovf_row(c, g, sn.ovf));
+    int hi = 0;                                            // local ids [0, cap + hi) may hold blocks
+    for (int j = 0; j < c.ovf_cap; j++)
+        if (sn.ovf[j] >= 0) hi = j + 1;
+    const size_t nb = (size_t)c.cap + hi, ns = nb * c.APAD;
     sn.P.resize(ns); sn.W.resize(ns); sn.Q.resize(ns); sn.N.resize(ns); sn.B.resize(ns); sn.busy.resize(ns);
     sn.legal.resize(nb * c.NW); sn.p64.resize(c.APAD);
-    SGO_HIP(hipMemcpy(sn.P.data(), c.cP + off * c.APAD, sizeof(float) * ns, hipMemcpyDeviceToHost));
-    SGO_HIP(hipMemcpy(sn.W.data(), c.cW + off * c.APAD, sizeof(float) * ns, hipMemcpyDeviceToHost));
-    SGO_HIP(hipMemcpy(sn.Q.data(), c.cQ + off * c.APAD, sizeof(float) * ns, hipMemcpyDeviceToHost));
-    SGO_HIP(hipMemcpy(sn.N.data(), c.cN + off * c.APAD, sizeof(int32_t) * ns, hipMemcpyDeviceToHost));
-    SGO_HIP(hipMemcpy(sn.B.data(), c.cB + off * c.APAD, sizeof(int32_t) * ns, hipMemcpyDeviceToHost));
-    SGO_HIP(hipMemcpy(sn.busy.data(), c.cBusy + off * c.APAD, ns, hipMemcpyDeviceToHost));
-    SGO_HIP(hipMemcpy(sn.legal.data(), c.legal + off * c.NW, sizeof(uint32_t) * nb * c.NW, hipMemcpyDeviceToHost));
+    // the private region in one piece, then every backed overflow block on its own
+    auto pull = [&](size_t dst_blk, size_t src_blk, size_t n_blk) -> int {
+        const size_t k = n_blk * c.APAD, d = dst_blk * c.APAD, o = src_blk * c.APAD;
+        SGO_HIP(hipMemcpy(sn.P.data() + d, c.cP + o, sizeof(float) * k, hipMemcpyDeviceToHost));
+        SGO_HIP(hipMemcpy(sn.W.data() + d, c.cW + o, sizeof(float) * k, hipMemcpyDeviceToHost));
+        SGO_HIP(hipMemcpy(sn.Q.data() + d, c.cQ + o, sizeof(float) * k, hipMemcpyDeviceToHost));
+        SGO_HIP(hipMemcpy(sn.N.data() + d, c.cN + o, sizeof(int32_t) * k, hipMemcpyDeviceToHost));
+        SGO_HIP(hipMemcpy(sn.B.data() + d, c.cB + o, sizeof(int32_t) * k, hipMemcpyDeviceToHost));
+        SGO_HIP(hipMemcpy(sn.busy.data() + d, c.cBusy + o, k, hipMemcpyDeviceToHost));
+        SGO_HIP(hipMemcpy(sn.legal.data() + dst_blk * c.NW, c.legal + src_blk * c.NW, sizeof(uint32_t) * n_blk * c.NW, hipMemcpyDeviceToHost));
+        return SGO_OK;
+    };
+    CK(pull(0, (size_t)g * c.cap, c.cap));
+    for (int j = 0; j < hi; j++)
+        if (sn.ovf[j] >= 0) CK(pull((size_t)c.cap + j, (size_t)c.G * c.cap + sn.ovf[j], 1));
     SGO_HIP(hipMemcpy(sn.p64.data(), c.rootP64 + (size_t)g * c.APAD, sizeof(double) * c.APAD, hipMemcpyDeviceToHost));
     return SGO_OK;
 }
@@ -1270,7 +1411,7 @@ int sgo_root_table(sgo_ctx *x, int slot, int32_t *N, float *W, float *Q, double 
     CK(snapshot(c, slot, sn));
     const int rb = sn.s.root_blk;
     std::vector<int32_t> bslot(1);
-    SGO_HIP(hipMemcpy(bslot.data(), c.bSlot + (size_t)slot * c.cap + rb, sizeof(int32_t), hipMemcpyDeviceToHost));
+    SGO_HIP(hipMemcpy(bslot.data(), c.bSlot + host_phys(c, slot, rb, sn.ovf), sizeof(int32_t), hipMemcpyDeviceToHost));
     const bool expanded = bslot[0] != -2;
     for (int a = 0; a < c.A; a++) {
         const size_t o = (size_t)rb * c.APAD + a;
@@ -1317,7 +1458,7 @@ int64_t sgo_tree_serialize(sgo_ctx *x, int slot, uint8_t *buf, int64_t cap, int6
     Snap sn;
     CK(snapshot(c, slot, sn));
     int32_t bslot = 0;
-    SGO_HIP(hipMemcpy(&bslot, c.bSlot + (size_t)slot * c.cap + sn.s.root_blk, sizeof(int32_t), hipMemcpyDeviceToHost));
+    SGO_HIP(hipMemcpy(&bslot, c.bSlot + host_phys(c, slot, sn.s.root_blk, sn.ovf), sizeof(int32_t), hipMemcpyDeviceToHost));
     int64_t off = 0, nn = 0, ne = 0;
     if (bslot != -2) ser_rec(c, sn, sn.s.root_blk, sn.s.root_f64 != 0, buf, cap, off, nn, ne);
     if (n_nodes) *n_nodes = nn;
@@ -1331,7 +1472,7 @@ int64_t sgo_tree_dump(sgo_ctx *x, int slot, uint8_t *buf, int64_t cap, int64_t *
     Snap sn;
     CK(snapshot(c, slot, sn));
     int32_t bslot = 0;
-    SGO_HIP(hipMemcpy(&bslot, c.bSlot + (size_t)slot * c.cap + sn.s.root_blk, sizeof(int32_t), hipMemcpyDeviceToHost));
+    SGO_HIP(hipMemcpy(&bslot, c.bSlot + host_phys(c, slot, sn.s.root_blk, sn.ovf), sizeof(int32_t), hipMemcpyDeviceToHost));
     int64_t off = 0, nn = 0, ne = 0;
     if (bslot != -2) ser_rec(c, sn, sn.s.root_blk, sn.s.root_f64 != 0, buf, cap, off, nn, ne, 0);
     if (n_nodes) *n_nodes = nn;
@@ -1347,7 +1488,9 @@ int sgo_game_board(sgo_ctx *x, int slot, int32_t *board17) {
     int32_t *d = nullptr;
     const size_t bsz = sizeof(int32_t) * (size_t)c.S * c.S * 17;
     SGO_HIP(hipMalloc((void **)&d, bsz));
-    int r = sgo_unpack_dev(c.S, 1, c.pos + ((size_t)slot * c.cap + s.root_blk) * c.RW, d, nullptr);
+    std::vector<int32_t> ovf;
+    CK(ovf_row(c, slot, ovf));
+    int r = sgo_unpack_dev(c.S, 1, c.pos + host_phys(c, slot, s.root_blk, ovf) * c.RW, d, nullptr);
     if (r == SGO_OK) {
         hipError_t e = hipMemcpy(board17, d, bsz, hipMemcpyDeviceToHost);
         if (e != hipSuccess) r = hip_fail(e, "hipMemcpy", __FILE__, __LINE__);

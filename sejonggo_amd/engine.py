@@ -59,7 +59,7 @@ class SelfPlayEngine(object):
     def __init__(self, net, size=None, n_games=None, sims=None, energy=None, stop_exploration=None, num_moves=None,
                  komi=None, self_play=True, dirichlet_alpha=None, dirichlet_epsilon=None, blocks_per_game=0,
                  device=0, symmetry="random1", layout="nhwc", dtype="fp16", seed=0, raise_on_error=True, packed=True,
-                 net2=None, graph=False, stream=None):
+                 net2=None, graph=False, stream=None, shared_blocks=0):
         """net2: a second net turns the slots into two-model EVALUATION games (evaluate_worker.py:137: model1 = `net`,
         model2 = `net2`, one tree per player, no Dirichlet noise); start them with start_eval_games."""
         import torch
@@ -92,7 +92,7 @@ class SelfPlayEngine(object):
                           stop_exploration=self.stop_exploration, num_moves=-1 if num_moves is None else num_moves,
                           blocks_per_game=blocks_per_game, self_play=1 if self_play else 0, komi=self.komi,
                           dirichlet_epsilon=conf['DIRICHLET_EPSILON'] if dirichlet_epsilon is None else dirichlet_epsilon,
-                          device_id=device, two_model=1 if self.two_model else 0)
+                          device_id=device, two_model=1 if self.two_model else 0, shared_blocks=int(shared_blocks))
         self.ctx = C.c_void_p(self.lib.sgo_ctx_create(C.byref(cfg)))
         if not self.ctx:
             raise _lib.SgoError("sgo_ctx_create failed: %s" % self.lib.sgo_last_error().decode())
@@ -524,6 +524,14 @@ class SelfPlayEngine(object):
         b = np.zeros((1, self.S, self.S, 17), dtype=np.int32)
         _lib.check(self.lib.sgo_game_board(self.ctx, C.c_int(slot), _lib.ptr(b)), "sgo_game_board")
         return b
+
+    def pool_info(self):
+        """Tree-block accounting of the context: private blocks per game, local ids per game, shared pool size, shared blocks
+        free now, fewest ever free."""
+        out = (C.c_int64 * 6)()
+        _lib.check(self.lib.sgo_pool_info(self.ctx, out, 6), "sgo_pool_info")
+        return {"private_per_game": int(out[0]), "ids_per_game": int(out[1]), "shared_blocks": int(out[2]),
+                "shared_free": int(out[3]), "shared_free_low_water": int(out[4]), "games": int(out[5])}
 
     def set_halt(self, slot, move_n):
         _lib.check(self.lib.sgo_set_halt(self.ctx, C.c_int(slot), C.c_int(move_n)), "sgo_set_halt")

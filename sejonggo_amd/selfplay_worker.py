@@ -103,7 +103,8 @@ def run_selfplay(gpu_id, model_indicator="BEST_SYM", n_games=None, games_per_gpu
     sym = conf.get('SYMMETRY_MODE', 'random1') if model_indicator.endswith("_SYM") else "identity"
     kw = dict(size=conf['SIZE'], n_games=G, sims=conf['MCTS_SIMULATIONS'], energy=conf['ENERGY'],
               stop_exploration=conf['STOP_EXPLORATION'], komi=conf['KOMI'], self_play=True, symmetry=sym,
-              device=gpu_id, seed=gpu_id, raise_on_error=False, blocks_per_game=int(conf.get('BLOCKS_PER_GAME', 0) or 0))
+              device=gpu_id, seed=gpu_id, raise_on_error=False, blocks_per_game=int(conf.get('BLOCKS_PER_GAME', 0) or 0),
+              shared_blocks=int(conf.get('SHARED_BLOCKS', 0) or 0))
     kw.update(engine_kwargs or {})
     # conf['ENGINE_HALVES'] = 2: two half-populations alternating on two streams, every round a captured launch chain
     # (engine.DualEngine); conf['ENGINE_GRAPH']: captured rounds on one population.  Both pay on small boards / shallow nets,

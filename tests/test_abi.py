@@ -42,7 +42,7 @@ def test_struct_layouts_match_header(tmp_path):
     import os
     import subprocess
     L = _lib()
-    assert ctypes.sizeof(L.Config) == 56
+    assert ctypes.sizeof(L.Config) == 64
     assert ctypes.sizeof(L.Status) == 48
     assert ctypes.sizeof(L.MoveRecord) == 24 == L.MOVE_RECORD_DTYPE.itemsize
     assert ctypes.sizeof(L.GameResult) == 40 == L.GAME_RESULT_DTYPE.itemsize

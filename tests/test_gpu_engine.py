@@ -224,7 +224,7 @@ def test_headline_batch_shape_equals_the_oracle_on_sampled_slots(L):
 TWO_MODEL_FILES = ["async_09.npz", "async_10.npz", "async_11.npz"]
 
 
-def _eval_engine(z, halt_at=None):
+def _eval_engine(z, halt_at=None, **kw):
     from sejonggo_amd.engine import SelfPlayEngine
     from sejonggo_amd.stub_nets import make_stub
     from tests.helpers import name_of
@@ -232,15 +232,16 @@ def _eval_engine(z, halt_at=None):
     kinds = name_of(z, "net").split("+")
     eng = SelfPlayEngine(make_stub(kinds[0], S), net2=make_stub(kinds[1], S), size=S, n_games=1, sims=int(z["sims"]),
                          energy=int(z["energy"]), stop_exploration=int(z["stop_exploration"]), num_moves=None if nm < 0 else nm,
-                         komi=float(z["komi"]), symmetry="identity")
+                         komi=float(z["komi"]), symmetry="identity", **kw)
     eng.start_eval_games([0], first_model=[0 if float(z["first_draw"]) < .5 else 1])
     if halt_at is not None:
         eng.set_halt(0, halt_at)
     return eng
 
 
+@pytest.mark.parametrize("pool", [{}, {"blocks_per_game": 12, "shared_blocks": 4000}], ids=["private_blocks", "shared_pool"])
 @pytest.mark.parametrize("fn", TWO_MODEL_FILES)
-def test_two_model_games_on_the_device_equal_the_reference(L, fn):
+def test_two_model_games_on_the_device_equal_the_reference(L, fn, pool):
     """Evaluation games (evaluate_worker.py:137) inside k_search: two root pointers per slot, the tree of the side not to
     move follows the move when it holds it, each evaluation row tagged with the model that is to move.  Against the
     reference's two-model goldens: every move, value, policy target and position, the searching player's whole tree after
@@ -248,7 +249,7 @@ def test_two_model_games_on_the_device_equal_the_reference(L, fn):
     from tests.helpers import name_of
     z = load(fn)
     S = int(z["size"])
-    eng = _eval_engine(z)
+    eng = _eval_engine(z, **pool)
     games = eng.run()
     assert len(games) == 1
     gd = games[0]
@@ -268,7 +269,7 @@ def test_two_model_games_on_the_device_equal_the_reference(L, fn):
     assert eng.status.total_evals == int(z["n_predict"]) and eng.status.none_events == int(z["none_events"])
     eng.close()
     for k in sorted(set([0, 1, 2, 3, n_moves // 2, n_moves - 2, n_moves - 1])):
-        eng = _eval_engine(z, halt_at=k)
+        eng = _eval_engine(z, halt_at=k, **pool)
         eng.run()
         t = eng.root_table(0)
         assert np.array_equal(t["N"], z["pm_N"][k]) and t["W"].tobytes() == z["pm_W"][k].tobytes(), k
@@ -514,6 +515,93 @@ def test_real_net_selfplay_runs_and_restarts(L):
     games2 = eng.run()
     assert len(games2) == 32
     eng.close()
+
+
+@pytest.mark.parametrize("fn", ["async_02.npz", "async_05.npz", "async_07.npz", "async_13.npz"])
+def test_golden_games_from_the_shared_block_pool(L, fn):
+    """The context-wide block pool: with a private region of the minimum size (energy + 2 blocks) practically every tree block
+    of the game is an overflow id backed by the shared pool -- taken one at a time inside k_search, handed back by the re-root's
+    mark / rebuild, merged into the free stack by k_compact.  The reference's goldens must come out move for move, with the
+    whole-tree hash after the last search (block ids never enter a serialised tree)."""
+    from sejonggo_amd.stub_nets import make_stub
+    z = load(fn)
+    S, E, sims = int(z["size"]), int(z["energy"]), int(z["sims"])
+    net = make_stub(bytes(z["net"]).decode(), S)
+    kw = dict(blocks_per_game=E + 2, shared_blocks=6 * sims + 64)
+    eng = _engine(z, net, **kw)
+    info = eng.pool_info()
+    assert info["private_per_game"] == E + 2 and info["shared_blocks"] == 6 * sims + 64 and info["ids_per_game"] > E + 2
+    games = eng.run()
+    gd = games[0]
+    assert len(gd["moves"]) == len(z["move_index"])
+    for i, mv in enumerate(gd["moves"]):
+        a = mv["move"][0] + S * mv["move"][1] if mv["move"][1] != S else S * S
+        assert a == z["move_index"][i] and mv["policy"].tobytes() == z["move_policy"][i].tobytes(), i
+        assert mv["value"].tobytes() == z["move_value"][i].tobytes(), i
+    assert gd["result"] == bytes(z["result"]).decode()
+    assert eng.status.total_evals == int(z["n_predict"]) and eng.status.none_events == int(z["none_events"])
+    after = eng.pool_info()
+    assert after["shared_free_low_water"] < after["shared_blocks"] - sims // 2            # the pool was really used ...
+    assert gd["blocks_high_water"] > E + 2
+    eng.start_games([0], noises=z["noises"][:1], uniforms=np.zeros((1, max(1, eng.max_moves))))
+    eng.step()
+    assert eng.pool_info()["shared_free"] >= after["shared_blocks"] - 2               # ... and a restart hands all of it back
+    eng.close()
+    k = len(z["move_index"]) - 1
+    eng = _engine(z, net, halt_at=k, **kw)
+    eng.run()
+    buf, nn, ne = eng.tree_serialize(0)
+    assert nn == z["pm_n_nodes"][k] and hashlib.sha1(buf.tobytes()).digest()[:16] == z["pm_tree_hash"][k].tobytes()
+    t = eng.root_table(0)
+    assert int(t["N"].sum()) > 0 and eng.board(0).shape == (1, S, S, 17)
+    eng.close()
+
+
+def test_many_games_share_one_pool_and_exhaustion_is_loud(L):
+    """32 concurrent games with 10-block private regions on one shared pool: (a) a pool that is large enough -- every game
+    equals the oracle's, whole trees included, although nearly all of their blocks are shared ones taken and returned move by
+    move; (b) a pool that is too small -- games fail with SGO_ERR_CAPACITY, loudly, whoever finishes still equals the oracle's,
+    and nothing hangs."""
+    from oracle import oracle as ora
+    from sejonggo_amd.engine import SelfPlayEngine
+    from sejonggo_amd.stub_nets import make_stub
+    S, sims, E, G, nm = 9, 64, 8, 32, 10
+    net = make_stub("hash", S)
+    rng = np.random.RandomState(41)
+    noises = rng.dirichlet([0.03] * (S * S + 1), size=G)
+    uni = rng.random_sample((G, nm))
+    for pool, expect_fail in ((G * 220, False), (G * 40, True)):
+        eng = SelfPlayEngine(net, size=S, n_games=G, sims=sims, energy=E, stop_exploration=4, num_moves=nm, komi=5.5,
+                             symmetry="identity", blocks_per_game=10, shared_blocks=pool, raise_on_error=False)
+        eng.start_games(np.arange(G), noises=noises, uniforms=uni)
+        for _ in range(2000):
+            st = eng.step()
+            if st.n_records >= G:
+                eng.drain()
+            if st.n_active == 0:
+                break
+        assert st.n_active == 0
+        eng.drain()
+        res = eng.results()
+        failed = [s for s in range(G) if res[s]["done"] < 0]
+        assert (len(failed) > 0) == expect_fail and all(res[s]["done"] == -201 for s in failed)
+        ok = [s for s in range(G) if res[s]["done"] == 1]
+        assert len(ok) + len(failed) == G and (expect_fail or len(ok) == G)
+        for s in ok:
+            g = ora.Game(S, sims, E, 4, nm, uniforms=uni[s], noises=noises[s:s + 1]).run(net)
+            moves = eng.records[s]
+            assert g.n_moves == len(moves) == nm, s
+            for i, mv in enumerate(moves):
+                m = g.move(i)
+                assert mv["action"] == m["action"] and mv["policy"].tobytes() == m["policy"].tobytes(), (s, i)
+            ta, _, _ = eng.tree_serialize(s)
+            tb, _, _ = g.tree_serialize()
+            assert ta.tobytes() == tb.tobytes(), s
+        info = eng.pool_info()
+        assert 0 <= info["shared_free_low_water"] < pool
+        if not expect_fail:
+            assert max(int(r["blocks_high_water"]) for r in res) > 60          # trees several times the private region
+        eng.close()
 
 
 def test_capacity_error_is_loud(L):

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--channels", type=int, default=64)
     ap.add_argument("--stop", type=int, default=30)
     ap.add_argument("--blocks-per-game", type=int, default=0, help="tree blocks per game (0 = the engine's default)")
+    ap.add_argument("--shared-blocks", type=int, default=0, help="tree blocks shared by all games (0 = the engine's default rule)")
     ap.add_argument("--policy-gain", type=float, default=1.0,
                     help="multiply the policy head's last layer: > 1 makes a random-init net's priors peaky, like a trained net's "
                          "(concentrated search -> the kept subtree holds most of the tree -> the block pool is stressed)")
@@ -86,6 +87,14 @@ def main():
             real_engine.__init__(self, *aa, **kk)
             probe["eng"] = self
             probe["cap"] = int(self.lib.sgo_blocks_per_game(self.ctx))
+            probe["pool0"] = self.pool_info()
+
+        def close(self):
+            try:
+                probe["pool1"] = self.pool_info()
+            except Exception:
+                pass
+            real_engine.close(self)
             probe.setdefault("hw", [])
 
         def step(self):
@@ -111,7 +120,7 @@ def main():
     hb = threading.Thread(target=heartbeat, daemon=True)
     hb.start()
     played = run_selfplay(0, "BEST_SYM", n_games=a.games, games_per_gpu=a.resident, on_game=on_game, stats=stats,
-                          engine_kwargs=dict({'blocks_per_game': a.blocks_per_game}, **({'num_moves': a.max_plies} if a.max_plies else {})))
+                          engine_kwargs=dict({'blocks_per_game': a.blocks_per_game, 'shared_blocks': a.shared_blocks}, **({'num_moves': a.max_plies} if a.max_plies else {})))
     stop.set()
     dt = time.time() - t0
     print("host seconds: stepping %.1f, turnover %.1f, waiting for writers at the end %.1f" % (
@@ -122,15 +131,15 @@ def main():
     print("played %d games in %.1f s: %d positions, %.1f positions/s; length min/mean/max %d/%.1f/%d" % (
         played, dt, lens.sum(), lens.sum() / dt, lens.min(), lens.mean(), lens.max()))
     allhw = np.array(probe.get("hw", [0]) or [0])
-    print("tree-block pool per game: %d blocks; high-water mark of finished games: max %d (%.0f %% of the pool), p99 %d, median %d" % (
-        probe.get("cap", -1), allhw.max(), 100.0 * allhw.max() / max(probe.get("cap", 1), 1), int(np.percentile(allhw, 99)),
-        int(np.median(allhw))))
+    print("private tree blocks per game: %d; high-water mark of finished games: max %d, p99 %d, median %d" % (
+        probe.get("cap", -1), allhw.max(), int(np.percentile(allhw, 99)), int(np.median(allhw))))
+    print("pool at the start:", probe.get("pool0"), "at the end:", probe.get("pool1"))
     if a.json:
         import json
         json.dump({"config": vars(a), "games_played": int(played), "games_started": a.games, "discarded": int(max(0, a.games - played)),
                    "seconds": dt, "positions": int(lens.sum()), "positions_per_sec": float(lens.sum() / dt),
                    "game_length": {"min": int(lens.min()), "mean": float(lens.mean()), "max": int(lens.max())},
-                   "blocks_per_game": probe.get("cap"), "pool_high_water": {"max": int(allhw.max()), "p99": int(np.percentile(allhw, 99)),
+                   "blocks_per_game": probe.get("cap"), "pool": probe.get("pool0"), "pool_at_end": probe.get("pool1"), "pool_high_water": {"max": int(allhw.max()), "p99": int(np.percentile(allhw, 99)),
                                                                            "median": int(np.median(allhw))},
                    "host_seconds": {k: stats.get(k) for k in ("step", "turnover", "writer_wait")}, "engine_steps": stats.get("steps"),
                    "end_reasons": {k: sum(1 for r in results if r.endswith(k)) for k in ("BOTH_PASSED", "PLAYED ALL MOVES", "resign")}},
