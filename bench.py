@@ -474,6 +474,7 @@ def run_rank(args):
             "engine": {"halves": args.halves, "captured_rounds": captured, "packed_input": bool(getattr(eng, "packed", False)),
                        "positions_in_window": int(moves), "games_restarted_in_window": restarts[0],
                        "host_seconds_outside_stepping_incl_warmup": host_s,
+                       "tree_blocks": (eng.halves[0].pool_info() if args.halves == 2 else eng.pool_info()),
                        "graph_replays": (sum(e.n_graph_replays for e in eng.halves) if args.halves == 2 else getattr(eng, "n_graph_replays", 0))},
             "rccl": dict(rccl, tuples_on_rank0=gathered[0],
                          gather="TupleGather: counts all_gather + padded gather to rank 0, 3-stage pipeline on a side stream"),

@@ -674,6 +674,9 @@ class DualEngine(object):
         e, local = self._half_of(slot)
         return e.board(local)
 
+    def pool_info(self):
+        return [e.pool_info() for e in self.halves]
+
     def advance_timing(self):
         t = [e.advance_timing() for e in self.halves]
         return tuple(sum(x[i] for x in t) for i in range(3))
