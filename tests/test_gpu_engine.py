@@ -701,8 +701,11 @@ def test_resign_and_no_noise_paths_equal_the_oracle(L):
     eng.close()
 
 
-def test_selfplay_worker_body_writes_samples(L, tmp_path):
-    """run_selfplay: directory reservation, engine loop with slot restarts, sample files in the reference's layout."""
+@pytest.mark.parametrize("halves", [1, 2], ids=["one_population", "two_half_populations"])
+def test_selfplay_worker_body_writes_samples(L, tmp_path, halves):
+    """run_selfplay: directory reservation, engine loop with slot restarts, sample files in the reference's layout -- on the
+    single-context engine (a small net on the tensor route) and on engine.DualEngine (conf['ENGINE_HALVES'] = 2: the resident
+    net's packed-record route, captured rounds, two streams; slots of both halves finish, restart and write)."""
     import os
     from sejonggo_amd import predicting_queue_worker as pq
     from sejonggo_amd import sgfsave
@@ -712,8 +715,8 @@ def test_selfplay_worker_body_writes_samples(L, tmp_path):
     keep = dict(conf)
     try:
         conf.update({'SIZE': 9, 'MCTS_SIMULATIONS': 16, 'ENERGY': 8, 'STOP_EXPLORATION': 2, 'N_GAMES': 6,
-                     'SELF_PLAY_DIR': str(tmp_path / "sp"), 'GAMES_PER_GPU': 4})
-        fnet, _ = build_fused_net(9, 1, 32, name="wk")
+                     'SELF_PLAY_DIR': str(tmp_path / "sp"), 'GAMES_PER_GPU': 4, 'ENGINE_HALVES': halves})
+        fnet, _ = build_fused_net(9, 1, 32 if halves == 1 else 256, name="wk")
         pq.set_model_factory(lambda kind: fnet)
         seen = []
         played = run_selfplay(0, "BEST_SYM", n_games=6, games_per_gpu=4, on_game=lambda g, gd: seen.append((g, len(gd['moves']))),
