@@ -66,7 +66,10 @@ def parse():
                     "k_search -> k_compact -> board_advance; no per-launch event timing in this mode")
     ap.add_argument("--halves", type=int, default=1, choices=[1, 2], help="2: the games run as two half-populations alternating on two "
                     "streams (engine.DualEngine; implies --graph 1)")
-    ap.add_argument("--gather-stream", default="side", choices=["side", "step"], help="stream of the tuple gather's copies and collectives")
+    ap.add_argument("--gather-stream", default="step", choices=["side", "step"],
+                    help="step: the gather's copies and collectives are ordered into the stepping stream (between two steps); side: on a side "
+                         "stream beside the step's kernels")
+    ap.add_argument("--gather-flush", type=int, default=0, help="1: complete every step's gather before the next step (blocking form, A/B)")
     ap.add_argument("--gather", type=int, default=1, help="0: skip the per-step tuple gather (A/B of its cost on small configurations)")
     ap.add_argument("--avg8-leg", type=int, default=1, help="headline configuration only: one warm-up + one step with 8-fold symmetry "
                     "averaging (BASELINE config 3 as written), reported as config3_avg8")
@@ -358,7 +361,7 @@ def run_rank(args):
                              device=local, seed=1234 + rank, graph=bool(args.graph))
     eng.start_games(np.arange(G))
     tdt = tuple_dtype(S)
-    exchange = TupleGather(tdt, side_stream=(args.gather_stream == "side"))          # side stream, per-batch staging: step k's gather overlaps the search of steps k+1, k+2
+    exchange = TupleGather(tdt, side_stream=(args.gather_stream == "side"))          # three-stage pipeline, recycled pinned staging
     gathered = [0]
     rccl = device_identities()           # which physical device every rank computes on (N ranks must show N distinct devices)
 
@@ -397,7 +400,7 @@ def run_rank(args):
             eng.records[s] = []
         h2 = time.perf_counter()
         if args.gather:
-            for got in exchange.submit(recs[:k]):
+            for got in exchange.submit(recs[:k]) + (exchange.flush() if args.gather_flush else []):
                 gathered[0] += 0 if got is None else len(got)
         h3 = time.perf_counter()
         host_s["drain"] += h1 - h0; host_s["tuples"] += h2 - h1; host_s["gather_submit"] += h3 - h2
@@ -477,7 +480,9 @@ def run_rank(args):
                        "tree_blocks": (eng.halves[0].pool_info() if args.halves == 2 else eng.pool_info()),
                        "graph_replays": (sum(e.n_graph_replays for e in eng.halves) if args.halves == 2 else getattr(eng, "n_graph_replays", 0))},
             "rccl": dict(rccl, tuples_on_rank0=gathered[0],
-                         gather="TupleGather: counts all_gather + padded gather to rank 0, 3-stage pipeline on a side stream"),
+                         gather="TupleGather: counts all_gather + padded gather to rank 0, 3-stage pipeline (host never waits on a fresh "
+                                "collective), %s" % ("beside the step on a side stream" if args.gather_stream == "side" else
+                                                     "ordered into the stepping stream between two steps")),
             "roofline_board_advance": {"bound": "hbm", "kernel": "board_advance in situ (make_play + legal set + history move of the step's leaf list; "
                                                                  "k_board_advance_rows, one half-wavefront per leaf, up to 32 768 leaves, k_board_advance above)",
                          "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,

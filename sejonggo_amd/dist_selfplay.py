@@ -118,7 +118,7 @@ def run_rank(backend="nccl", sync_every=4, max_steps=None):
     pending, outbox = [], []
     played = written = steps = 0
     dev = torch.device("cuda", local) if backend == "nccl" else torch.device("cpu")
-    exchange = TupleGather(tuple_dtype(S), device=dev)     # side stream + per-batch staging: a meeting's gather overlaps the next steps
+    exchange = TupleGather(tuple_dtype(S), device=dev)     # three-stage pipeline: the host never waits for a collective it has just issued
     try:
         active = fill(range(G))
         idle = G - active

@@ -167,10 +167,13 @@ class TupleGather(object):
     On RCCL the gather is 7 concurrent point-to-point transfers into rank 0 over the xGMI mesh; on gloo (CPU tensors) the
     same stages run without a stream.  `submit` returns the batches that completed (possibly none); `flush` drains."""
 
-    def __init__(self, dtype, device=None, dst=0, side_stream=True):
-        """side_stream=False queues the copies and collectives on the caller's current (stepping) stream instead: still no host
-        wait on a collective just issued (the three stages stay), but the few microseconds of GPU work sit between two steps
-        rather than beside them -- see DESIGN.md §6 for the measured difference on small configurations."""
+    def __init__(self, dtype, device=None, dst=0, side_stream=False):
+        """side_stream=True: copies on a side stream, collectives left to run BESIDE the stepping stream's kernels (SURVEY.md
+        §8e's form).  side_stream=False (default): the same three stages, but every collective is ordered INTO the stepping
+        stream (its next kernels queue behind it) -- the host still never waits for a collective it has just issued, and the
+        ~0.1 ms of copies + collectives sit between two steps instead of beside them.  Why the default: on this stack a
+        communication kernel that runs beside the convolutions slows them by far more than it takes alone (DESIGN.md §6:
+        config 2, one rank: 27 ms per step without the gather, 35-48 ms with it beside the step, 28 ms with it between steps)."""
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -217,6 +220,8 @@ class TupleGather(object):
             b["counts"] = [torch.zeros(1, dtype=torch.int64, device=self.dev) for _ in range(self.world)]
             b["work"] = dist.all_gather(b["counts"], cnt, async_op=True)
             b["cnt"] = cnt
+            if self.side is None:
+                b["work"].wait()          # GPU-side ordering only: the stepping stream runs its next kernels BEHIND the collective
         return b
 
     def _stage2(self, b):
@@ -236,6 +241,8 @@ class TupleGather(object):
                 b["work"] = dist.gather(block, b["outs"], dst=self.dst, async_op=True)
             else:
                 b["work"] = dist.gather(block, None, dst=self.dst, async_op=True)
+            if self.side is None:
+                b["work"].wait()
         b["stage"] = 2
 
     def _stage3(self, b):

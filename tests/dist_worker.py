@@ -30,7 +30,7 @@ def main():
     empty = gather_tuples(t[:0] if rank == world - 1 else t[:1])   # one rank contributes nothing
     # the pipelined form the self-play loops use: four batches of different lengths (one of them empty on the last rank),
     # nothing completes before the third submit, batches come back in submit order
-    tg = TupleGather(dt)
+    tg = TupleGather(dt, side_stream=(os.environ.get('SGO_TEST_SIDE_STREAM', '1') == '1'))   # the side-stream form (a CUDA stream under nccl)
     done_at, got = [], []
     for k in range(4):
         m = 0 if (k == 2 and rank == world - 1) else min(n, 1 + k + rank)
