@@ -66,9 +66,10 @@ def parse():
                     "k_search -> k_compact -> board_advance; no per-launch event timing in this mode")
     ap.add_argument("--halves", type=int, default=1, choices=[1, 2], help="2: the games run as two half-populations alternating on two "
                     "streams (engine.DualEngine; implies --graph 1)")
-    ap.add_argument("--gather-stream", default="step", choices=["side", "step"],
-                    help="step: the gather's copies and collectives are ordered into the stepping stream (between two steps); side: on a side "
-                         "stream beside the step's kernels")
+    ap.add_argument("--gather-stream", default="side", choices=["side", "step"],
+                    help="side: the gather's copies and collectives run on a side stream beside the step's kernels; step: ordered into the "
+                         "stepping stream (between two steps)")
+    ap.add_argument("--gather-collective", default="gather", choices=["gather", "all_gather"])
     ap.add_argument("--gather-flush", type=int, default=0, help="1: complete every step's gather before the next step (blocking form, A/B)")
     ap.add_argument("--gather", type=int, default=1, help="0: skip the per-step tuple gather (A/B of its cost on small configurations)")
     ap.add_argument("--avg8-leg", type=int, default=1, help="headline configuration only: one warm-up + one step with 8-fold symmetry "
@@ -361,7 +362,7 @@ def run_rank(args):
                              device=local, seed=1234 + rank, graph=bool(args.graph))
     eng.start_games(np.arange(G))
     tdt = tuple_dtype(S)
-    exchange = TupleGather(tdt, side_stream=(args.gather_stream == "side"))          # three-stage pipeline, recycled pinned staging
+    exchange = TupleGather(tdt, side_stream=(args.gather_stream == "side"), collective=args.gather_collective)          # three-stage pipeline, recycled pinned staging
     gathered = [0]
     rccl = device_identities()           # which physical device every rank computes on (N ranks must show N distinct devices)
 

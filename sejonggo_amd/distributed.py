@@ -156,29 +156,36 @@ def gather_tuples(tuples, device=None, dst=0):
 
 
 class TupleGather(object):
-    """Variable-length gather of (s, pi, z) tuples to rank `dst`, OFF the critical path: every batch goes
-    through three stages, one per `submit`, all on a side stream with their own staging buffers, so the exchange of step
-    k overlaps the search of steps k+1 and k+2 and the stepping thread never waits for a collective it has just issued:
+    """Variable-length gather of (s, pi, z) tuples to rank `dst` that keeps the HOST off the critical path:
+    every batch goes through three stages, one per `submit`, so the stepping thread never waits for a collective it has just
+    issued:
 
       stage 1 (submit k)    payload -> pinned host block -> device block (async copy); all_gather of the per-rank counts
       stage 2 (submit k+1)  counts read (issued one step ago: complete), blocks padded to the largest, dist.gather to dst
       stage 3 (submit k+2)  dst: device -> pinned host copy, trimmed per rank, handed to the caller in submit order
 
-    On RCCL the gather is 7 concurrent point-to-point transfers into rank 0 over the xGMI mesh; on gloo (CPU tensors) the
-    same stages run without a stream.  `submit` returns the batches that completed (possibly none); `flush` drains."""
+    On RCCL the gather is 7 concurrent point-to-point transfers into rank 0 over the xGMI mesh (collective="all_gather": one
+    ncclAllGather of the padded blocks instead); on gloo (CPU tensors) the same stages run without a stream.  Every tensor a
+    collective touches lives in one of three ROTATING SLOTS that are allocated once and only ever grow: a tensor that is freed
+    after a collective used it on the communication stream makes the caching allocator poll that stream's events on every
+    later allocation (record_stream).  Host-side staging is plain memcpy (see _stage1).  `submit` returns the batches that
+    completed (possibly none); `flush` drains."""
 
-    def __init__(self, dtype, device=None, dst=0, side_stream=False):
-        """side_stream=True: copies on a side stream, collectives left to run BESIDE the stepping stream's kernels (SURVEY.md
-        §8e's form).  side_stream=False (default): the same three stages, but every collective is ordered INTO the stepping
-        stream (its next kernels queue behind it) -- the host still never waits for a collective it has just issued, and the
-        ~0.1 ms of copies + collectives sit between two steps instead of beside them.  Why the default: on this stack a
-        communication kernel that runs beside the convolutions slows them by far more than it takes alone (DESIGN.md §6:
-        config 2, one rank: 27 ms per step without the gather, 35-48 ms with it beside the step, 28 ms with it between steps)."""
+    SLOTS = 3
+
+    def __init__(self, dtype, device=None, dst=0, side_stream=True, collective="gather"):
+        """side_stream=True (default): copies on a side stream, collectives left to run BESIDE the stepping stream's kernels
+        (SURVEY.md §8e's form: step k's gather overlaps the search of steps k+1, k+2).  side_stream=False: the same three stages,
+        but every collective is ordered INTO the stepping stream (its next kernels queue behind it).  Measured equal within
+        noise at config 2 (9 380 vs 9 423 positions/s, 9 489 without any gather)."""
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
         self.dtype = np.dtype(dtype)
         self.dst = dst
+        # "gather": dist.gather to dst; "all_gather": ncclAllGather of the padded blocks (every rank receives everything, only
+        # dst keeps it)
+        self.collective = collective
         self.world, self.rank = dist.get_world_size(), dist.get_rank()
         self.dev = device if device is not None else _comm_device()
         self.on_gpu = self.dev.type == "cuda"
@@ -186,19 +193,40 @@ class TupleGather(object):
         self.inflight = []          # batches in submit order, each a dict with its stage
         self.n_submitted = 0
         self.bytes_gathered = 0
-        self._pinned = []           # recycled pinned staging blocks (a batch holds its blocks until its copies have run)
+        self.slots = [None] * self.SLOTS
 
-    def _host_block(self, nbytes):
-        """A pinned (page-locked) uint8 block of at least nbytes from the recycling list; allocating one costs a system call."""
+    # -- persistent buffers ---------------------------------------------------------------------------------------
+    def _slot(self, k, nbytes):
+        """Slot k with room for nbytes per rank: allocated on first use, re-allocated (larger) only when a batch outgrows it."""
         torch = self.torch
-        for i, t in enumerate(self._pinned):
-            if t.numel() >= nbytes:
-                return self._pinned.pop(i)
-        return torch.empty(max(int(nbytes * 1.5), 4096), dtype=torch.uint8, pin_memory=self.on_gpu)
+        sl = self.slots[k]
+        if sl is None or sl["cap"] < nbytes:
+            cap = max(4096, int(nbytes * 1.5))
+            holds = self.collective == "all_gather" or self.rank == self.dst
+            sl = {"cap": cap,
+                  "host_in": torch.empty(cap, dtype=torch.uint8, pin_memory=self.on_gpu),
+                  "block": torch.zeros(cap, dtype=torch.uint8, device=self.dev),
+                  "cnt_host": torch.zeros(1, dtype=torch.int64, pin_memory=self.on_gpu),
+                  "cnt": torch.zeros(1, dtype=torch.int64, device=self.dev),
+                  "counts": [torch.zeros(1, dtype=torch.int64, device=self.dev) for _ in range(self.world)],
+                  "outs": [torch.zeros(cap, dtype=torch.uint8, device=self.dev) for _ in range(self.world)] if holds else None,
+                  "host_out": torch.empty(cap * self.world, dtype=torch.uint8, pin_memory=self.on_gpu) if holds else None}
+            self.slots[k] = sl
+        return sl
 
-    def _recycle(self, *blocks):
-        self._pinned.extend(b for b in blocks if b is not None)
-        del self._pinned[:-8]
+    def _grow(self, b, nbytes):
+        """Stage 2 found a peer's batch larger than this slot: move the batch to a bigger slot (its own payload is re-staged
+        from the pinned copy)."""
+        old = b["slot"]
+        k = b["k"]
+        self.slots[k] = None
+        sl = self._slot(k, nbytes)
+        if b["nbytes"]:
+            sl["host_in"].numpy()[:b["nbytes"]] = old["host_in"].numpy()[:b["nbytes"]]
+            sl["block"][:b["nbytes"]].copy_(sl["host_in"][:b["nbytes"]], non_blocking=True)
+        b["slot"] = sl
+        b["keep"] = old            # until the batch completes: the old tensors may still be in use by an earlier copy
+        return sl
 
     # -- stages ---------------------------------------------------------------------------------------------------
     def _stream(self):
@@ -209,35 +237,40 @@ class TupleGather(object):
         torch, dist = self.torch, self.dist
         n = len(tuples)
         raw = np.ascontiguousarray(tuples).view(np.uint8).reshape(-1)
-        host = self._host_block(raw.size)
+        k = self.n_submitted % self.SLOTS
+        sl = self._slot(k, raw.size)
+        # plain memcpy through the numpy views of the pinned blocks: a torch CPU copy_ of this size goes to the intra-op thread
+        # pool, whose workers then spin for a while on every core of the GPU box's CPU share -- ONE such copy per 27-ms step
+        # slowed the stepping thread's kernel launches by 30-60 % at config 2 (tools/debug_gather.py: 26.1 -> 42.2 ms per move)
         if raw.size:
-            host[:raw.size].copy_(torch.from_numpy(raw))
-        b = {"n": n, "nbytes": raw.size, "stage": 1}
+            sl["host_in"].numpy()[:raw.size] = raw
+        sl["cnt_host"].numpy()[0] = n
+        b = {"n": n, "nbytes": raw.size, "stage": 1, "slot": sl, "k": k}
         with self._stream():
-            b["payload"] = host[:max(raw.size, 1)].to(self.dev, non_blocking=True) if self.on_gpu else host[:max(raw.size, 1)].clone()
-            b["host"] = host                                            # the pinned block is recycled once the copy has run (stage 2)
-            cnt = torch.tensor([n], dtype=torch.int64).to(self.dev, non_blocking=True)
-            b["counts"] = [torch.zeros(1, dtype=torch.int64, device=self.dev) for _ in range(self.world)]
-            b["work"] = dist.all_gather(b["counts"], cnt, async_op=True)
-            b["cnt"] = cnt
+            if raw.size:
+                sl["block"][:raw.size].copy_(sl["host_in"][:raw.size], non_blocking=True)
+            sl["cnt"].copy_(sl["cnt_host"], non_blocking=True)
+            b["work"] = dist.all_gather(sl["counts"], sl["cnt"], async_op=True)
             if self.side is None:
                 b["work"].wait()          # GPU-side ordering only: the stepping stream runs its next kernels BEHIND the collective
         return b
 
     def _stage2(self, b):
-        torch, dist = self.torch, self.dist
+        dist = self.dist
         with self._stream():
-            b["work"].wait()                                             # makes the SIDE stream wait; the stepping stream never depends on a collective
-            counts = [int(c.item()) for c in b["counts"]]                # issued a step ago: no wait worth the name; orders the payload copy too
-            self._recycle(b.pop("host", None))
+            b["work"].wait()                                             # with a side stream: makes IT wait, never the stepping stream
+            sl = b["slot"]
+            counts = [int(c.item()) for c in sl["counts"]]               # issued a step ago: no wait worth the name
             b["count_list"] = counts
             width = max(max(counts), 1) * self.dtype.itemsize
-            block = torch.zeros(width, dtype=torch.uint8, device=self.dev)
-            if b["nbytes"]:
-                block[:b["nbytes"]].copy_(b["payload"][:b["nbytes"]], non_blocking=True)
-            b["block"] = block
-            if self.rank == self.dst:
-                b["outs"] = [torch.empty_like(block) for _ in range(self.world)]
+            if width > sl["cap"]:
+                sl = self._grow(b, width)
+            block = sl["block"][:width]
+            if self.collective == "all_gather":
+                b["outs"] = [o[:width] for o in sl["outs"]]
+                b["work"] = dist.all_gather(b["outs"], block, async_op=True)
+            elif self.rank == self.dst:
+                b["outs"] = [o[:width] for o in sl["outs"]]
                 b["work"] = dist.gather(block, b["outs"], dst=self.dst, async_op=True)
             else:
                 b["work"] = dist.gather(block, None, dst=self.dst, async_op=True)
@@ -252,22 +285,22 @@ class TupleGather(object):
             b["work"].wait()
         if self.rank != self.dst:
             return None
+        sl = b["slot"]
         with self._stream():
-            hosts = []
+            off, spans = 0, []
             for o, c in zip(b["outs"], b["count_list"]):
                 nb = c * self.dtype.itemsize
-                h = self._host_block(nb)
                 if nb:
-                    h[:nb].copy_(o[:nb], non_blocking=True)
-                hosts.append((h, nb))
+                    sl["host_out"][off:off + nb].copy_(o[:nb], non_blocking=True)
+                spans.append((off, nb))
+                off += nb
             if self.side is not None:
                 self.side.synchronize()                                  # this batch's own copies; the compute stream is not involved
             elif self.on_gpu:
                 torch.cuda.current_stream().synchronize()
-        parts = [np.frombuffer(h.numpy()[:nb].tobytes(), dtype=self.dtype) for h, nb in hosts]
-        self._recycle(*[h for h, _ in hosts])
-        self.bytes_gathered += sum(nb for _, nb in hosts)
-        return np.concatenate(parts) if parts else np.zeros(0, dtype=self.dtype)
+        out = np.frombuffer(sl["host_out"].numpy()[:off].tobytes(), dtype=self.dtype)
+        self.bytes_gathered += off
+        return out
 
     # -- driver ---------------------------------------------------------------------------------------------------
     def _advance(self, drain=False):
@@ -293,6 +326,7 @@ class TupleGather(object):
         that completed during the call: on `dst` the gathered arrays in submit order, elsewhere Nones."""
         assert tuples.dtype == self.dtype
         done = self._advance()
+        assert len(self.inflight) < self.SLOTS
         self.inflight.append(self._stage1(tuples))
         self.n_submitted += 1
         return done
