@@ -36,7 +36,7 @@ def main():
 
     arms = [("k_conv8w, identity tile order", 0), ("k_conv8w, XCD-contiguous tiles", 1), ("k_conv4w (2 workgroups / CU)", 16 + 7)]
     if os.environ.get("SGO_AB_VARIANTS"):          # library built with -DSGO_CONV4W_VARIANTS
-        arms += [("k_conv4w var %d" % v, 16 + v) for v in (0, 4, 5, 6)]
+        arms += [("k_conv4w var %d" % v, 16 + v) for v in [int(a) for a in os.environ["SGO_AB_VARIANTS"].split(",") if a.isdigit() and int(a) != 1] or (0, 4, 5, 6)]
     outs = {}
     for name, mode in arms:
         select(mode)
