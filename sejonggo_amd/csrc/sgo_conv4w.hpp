@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void k_conv4w(const char *__restrict__ xb, 
 #define S4_LDS16(off) (*reinterpret_cast<const half8 *>(smem + (off)))
 #define S4_SHIFT(T) (((T) / 3 == 0 ? -W : (T) / 3 == 2 ? W : 0) + (T) % 3 - 1)
 #define S4_READ_A(G, T)                                                                               \
-    do {                                                                                              \
+    if (!(VAR & 32)) do {                                                                             \
         int ra_ = rowA;                                                                               \
         asm volatile("" : "+v"(ra_));                                                                 \
         const int rl_ = ra_ + S4_SHIFT(T);                                                            \
@@ -190,18 +190,22 @@ __global__ __launch_bounds__(256, 2) void k_conv4w(const char *__restrict__ xb, 
         }                                                                                             \
     } while (0)
 #define S4_READ_B(BUF, G, dst)                                                                        \
-    _Pragma("unroll") for (int nt_ = 0; nt_ < 2; nt_++) {                                             \
+    if (!(VAR & 32)) _Pragma("unroll") for (int nt_ = 0; nt_ < 2; nt_++) {                            \
         dst[nt_][0] = S4_LDS16(((BUF) ? LB1 : LB0) + (G) * 8192 + nt_ * 2048 + rdB0);                 \
         dst[nt_][1] = S4_LDS16(((BUF) ? LB1 : LB0) + (G) * 8192 + nt_ * 2048 + rdB1);                 \
     }
 #define S4_PRIO(x) __builtin_amdgcn_s_setprio(x)
+// ABLATION bits (timing only, wrong results; -DSGO_CONV4W_VARIANTS builds): 16 no MFMAs, 32 no fragment reads, 64 no weight
+// staging, 128 no barriers inside the K loop
 #define S4_MFMA(QM, QN, wfrag)                                                                         \
+    if (!(VAR & 16))                                                                                   \
     _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ks_++) _Pragma("unroll") for (int mt_ = 0; mt_ < 4; mt_++) \
         _Pragma("unroll") for (int nt_ = 0; nt_ < 2; nt_++) acc[QM][QN][mt_][nt_] =                    \
             __builtin_amdgcn_mfma_f32_16x16x32_f16(wfrag[nt_][ks_], pa[mt_][ks_], acc[QM][QN][mt_][nt_], 0, 0, 0)
 
 // One K-tile, tap T of chunk cc (runtime), K-tile index t = 9 cc + T; buffer parity = t & 1 = (cc + T) & 1 -> the caller
 // instantiates both parities (CP = cc & 1).
+#define S4_KBARRIER() do { if (!(VAR & 128)) { S4_BARRIER(); } } while (0)
 #define S4_TILE(T, CP)                                                                                    \
     do {                                                                                                  \
         constexpr int BUF_ = ((T) + (CP)) & 1, T2_ = ((T) + 2) % 9, CARRY_ = ((T) + 2) / 9;               \
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void k_conv4w(const char *__restrict__ xb, 
         S4_LGKM0();                                                                                       \
         /* barrier 1: every wave has read weights[t] (its buffer may be refilled) and, in the last tap, the window rows */ \
         /* [0, 128) for the last time */                                                                  \
-        S4_BARRIER();                                                                                     \
+        S4_KBARRIER();                                                                                     \
         /* last tap (shift +W+1): phase B reads window rows >= 128 + 2 (W + 1) only, so rows [0, 128) = pieces 0..15 are */ \
         /* dead from here on (whatever W) and take the next chunk's window one phase early: 4 DMAs per wave */ \
         if ((VAR & 4) && boundary_) S4_STAGE_WP((cc + 1) * 128, 0, 4);                                    \
@@ -227,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void k_conv4w(const char *__restrict__ xb, 
         __builtin_amdgcn_sched_barrier(0);                                                                \
         if ((VAR & 6) == 6 && (T) == 0 && cc > 0) {   /* first tap of a restaged chunk: phase A read rows [0, 128) only (the */ \
             S4_VMWAIT(0);                        /* early pieces); the late pieces, issued a whole phase ago, are needed from here */ \
-            S4_BARRIER();                                                                                 \
+            S4_KBARRIER();                                                                                 \
         }                                                                                                 \
         S4_READ_A(1, T);                                                                                  \
         if (VAR & 8) {                                                                                    \
@@ -243,8 +247,10 @@ __global__ __launch_bounds__(256, 2) void k_conv4w(const char *__restrict__ xb, 
             }                                                                                             \
         } else if (!last2_) {                                                                             \
             const int koff_ = T2_ * (CIN * 2) + (cc + CARRY_) * 128;                                      \
-            S4_STAGE_BK(BUF_, 0, koff_);                                                                  \
-            S4_STAGE_BK(BUF_, 1, koff_);                                                                  \
+            if (!(VAR & 64)) {                                                                            \
+                S4_STAGE_BK(BUF_, 0, koff_);                                                              \
+                S4_STAGE_BK(BUF_, 1, koff_);                                                              \
+            }                                                                                             \
             /* weights[t+1] (issued one K-tile ago) have landed; younger: weights[t+2] and this tap's early window pieces */ \
             if ((VAR & 4) && boundary_) S4_VMWAIT(8);                                                     \
             else S4_VMWAIT(4);                                                                            \
@@ -252,7 +258,7 @@ __global__ __launch_bounds__(256, 2) void k_conv4w(const char *__restrict__ xb, 
             S4_VMWAIT(0);                        /* K-tile 34: K-tile 35's weights */                       \
         }                                                                                                 \
         S4_LGKM0();                                                                                       \
-        S4_BARRIER();                            /* barrier 2: weights[t+1] visible to all; this tap's window reads retired */ \
+        S4_KBARRIER();                            /* barrier 2: weights[t+1] visible to all; this tap's window reads retired */ \
         if (boundary_) S4_STAGE_WP((cc + 1) * 128, (VAR & 4) ? 4 : 0, 10);                                \
         S4_PRIO(S4_MFMA_PRIO);                                                                            \
         S4_MFMA(1, 1, whi);                                                                               \
@@ -268,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void k_conv4w(const char *__restrict__ xb, 
             else if (nlate == 5) S4_VMWAIT(9);                                                            \
             else if (nlate == 4) S4_VMWAIT(8);                                                            \
             else S4_VMWAIT(0);                                                                            \
-            S4_BARRIER();                        /* rows [0, 128) of the next chunk's window are in place */ \
+            S4_KBARRIER();                        /* rows [0, 128) of the next chunk's window are in place */ \
         }                                                                                                 \
     } while (0)
 
@@ -449,6 +455,13 @@ static inline int launch(int n, int h, int w, const void *x, const void *wgt, co
     case 5: return launch_var<5>(n, h, w, x, wgt, bias, skip, y, st);
     case 6: return launch_var<6>(n, h, w, x, wgt, bias, skip, y, st);
     case 15: return launch_var<15>(n, h, w, x, wgt, bias, skip, y, st);
+    case 23: return launch_var<23>(n, h, w, x, wgt, bias, skip, y, st);      // ablations (wrong results, timing only)
+    case 39: return launch_var<39>(n, h, w, x, wgt, bias, skip, y, st);
+    case 71: return launch_var<71>(n, h, w, x, wgt, bias, skip, y, st);
+    case 135: return launch_var<135>(n, h, w, x, wgt, bias, skip, y, st);
+    case 87: return launch_var<87>(n, h, w, x, wgt, bias, skip, y, st);
+    case 231: return launch_var<231>(n, h, w, x, wgt, bias, skip, y, st);
+    case 103: return launch_var<103>(n, h, w, x, wgt, bias, skip, y, st);
 #endif
     default: return launch_var<7>(n, h, w, x, wgt, bias, skip, y, st);
     }
@@ -459,6 +472,7 @@ static inline int launch(int n, int h, int w, const void *x, const void *wgt, co
 #undef S4_AS1
 #undef S4_AS3
 #undef S4_BARRIER
+#undef S4_KBARRIER
 #undef S4_DS_READ128
 #undef S4_DS_READ64
 #undef S4_DS_WRITE64
