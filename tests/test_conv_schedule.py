@@ -188,7 +188,7 @@ def test_conv4w_model_is_in_step_with_the_kernel_source():
     assert "if (boundary_) S4_STAGE_WP((cc + 1) * 128, (VAR & 4) ? 4 : 0, 10);" in s
     assert "if ((VAR & 6) != 6) S4_VMWAIT(0);" in s
     assert "else if (nlate == 6) S4_VMWAIT(10);" in s and "else if (nlate == 5) S4_VMWAIT(9);" in s and "else if (nlate == 4) S4_VMWAIT(8);" in s
-    assert re.search(r"if \(\(VAR & 6\) == 6 && \(T\) == 0 && cc > 0\) \{[^}]*S4_VMWAIT\(0\);[^}]*S4_BARRIER\(\);", s)
+    assert re.search(r"if \(\(VAR & 6\) == 6 && \(T\) == 0 && cc > 0\) \{[^}]*S4_VMWAIT\(0\);[^}]*S4_KBARRIER\(\);", s)
     assert "for (int pc = 4; pc < 10; pc++) nlate += ((pc * 4 + wid) * 8 < NROWS) ? 1 : 0;" in s
     assert "const int id_ = pc_ * 4 + swid;" in s and "if (id_ * 8 < NROWS)" in s
     assert "S4_VMWAIT(0);                        /* K-tile 34: K-tile 35's weights */" in s
