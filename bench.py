@@ -512,12 +512,12 @@ def run_rank(args):
                                "tail_split": {"enabled": bool(getattr(net, "tail_split", False)), "side_stream_flops": conv_side_fl,
                                               "note": "8 192 positions = 9 248 tiles = 36.1 rounds of 256 workgroups; the 29 positions "
                                                       "beyond 36 whole rounds run on a side stream inside the main launches' wall time"}}
-            pc = os.path.join(ROOT, "profiles", "r02_pmc_conv.json")
+            pc = os.path.join(ROOT, "profiles", "r03_pmc_conv.json")
             if os.path.isfile(pc) and (S, G, E) == (19, 1024, 8):
                 try:   # HBM bytes per 8192-batch launch: separate --pmc passes; FETCH_SIZE doubled (gfx950 wide-read correction)
                     j = json.load(open(pc))
                     out["roofline"]["traffic"] = (2 * j["FETCH_SIZE"]["mean"] + j["WRITE_SIZE"]["mean"]) * 1024
-                    out["roofline"]["traffic_source"] = ("profiles/r02_pmc_conv.json (tools/pmc_conv_traffic.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                    out["roofline"]["traffic_source"] = ("profiles/r03_pmc_conv.json (tools/pmc_conv_traffic.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                                                          "passes of this command, 8192-position launches; algorithmic x + skip + y + weights = 3.63 GB with skip, 2.42 GB without)")
                 except Exception:
                     pass

@@ -797,6 +797,19 @@ __global__ __launch_bounds__(64) void k_search(Ctx c, const float *policy, const
 #ifdef SGO_KSEARCH_PROFILE
     if (lane == 0) atomicAdd(&c.counters->dbg[4], 1ull);
 #endif
+    // a game that has just failed (its tree is abandoned; the slot waits for a restart) hands its shared blocks back at once,
+    // so that one starved game does not starve its neighbours for the steps until the host reacts
+    if (st.error && st.ovf_hi > 0) {
+        for (int j = lane; j < st.ovf_hi; j += 64) {
+            const size_t mi = (size_t)g * c.ovf_cap + j;
+            const int ob = c.ovfMap[mi];
+            if (ob >= 0) {
+                c.poolRet[atomicAdd(&c.poolCtl[1], 1)] = ob;
+                c.ovfMap[mi] = -1;
+            }
+        }
+        st.ovf_hi = 0;
+    }
     if (lane == 0) c.gs[g] = st;
 }
 
@@ -1374,6 +1387,7 @@ static int ovf_row(Ctx &c, int g, std::vector<int32_t> &ovf) {
 static int snapshot(Ctx &c, int g, Snap &sn) {
     SGO_HIP(hipDeviceSynchronize());
     SGO_HIP(hipMemcpy(&sn.s, c.gs + g, sizeof(GameState), hipMemcpyDeviceToHost));
+    if (sn.s.error) { set_error("this slot's game failed (its tree was abandoned and its shared blocks released)"); return SGO_ERR_STATE; }
     CK(ovf_row(c, g, sn.ovf));
     int hi = 0;                                            // local ids [0, cap + hi) may hold blocks
     for (int j = 0; j < c.ovf_cap; j++)

@@ -6,7 +6,7 @@ TAG=${1:-r02}
 cd /tmp; export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmcc_$c
-  timeout -k 10 400 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "k_conv[48]w" --output-format csv -d /tmp/pmcc_$c -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-baseline 0 --saturated 0 --steady-state 0 > /tmp/pmcc_$c.log 2>&1
+  timeout -k 10 400 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "k_conv[48]w" --output-format csv -d /tmp/pmcc_$c -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-baseline 0 --saturated 0 --steady-state 0 --avg8-leg 0 > /tmp/pmcc_$c.log 2>&1
   echo "pass $c exit=$?"
 done
 python3 - <<PY

@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=${1:-r01}
 cd /tmp; export TMPDIR=/tmp
 rm -rf /tmp/pmc_net
-timeout -k 10 500 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_MFMA GRBM_GUI_ACTIVE --kernel-trace --kernel-include-regex "k_conv[48]w" --output-format csv -d /tmp/pmc_net -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-baseline 0 --saturated 0 --steady-state 0 > /tmp/pmc_net.log 2>&1
+timeout -k 10 500 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_MFMA GRBM_GUI_ACTIVE --kernel-trace --kernel-include-regex "k_conv[48]w" --output-format csv -d /tmp/pmc_net -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-baseline 0 --saturated 0 --steady-state 0 --avg8-leg 0 > /tmp/pmc_net.log 2>&1
 echo "exit=$?"
 python3 - <<PY
 import csv, glob, json, collections
