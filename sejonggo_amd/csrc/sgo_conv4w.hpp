@@ -213,6 +213,26 @@ __global__ __launch_bounds__(256, 2) void k_conv4w(const char *__restrict__ xb, 
         asm volatile("" : "+s"(swid));                                                                    \
         const bool last2_ = cc == 3 && (T) >= 7;    /* K-tiles 34, 35: nothing left to stage */           \
         const bool boundary_ = (T) == 8 && cc < 3;  /* last tap of a chunk that has a successor */        \
+        if (VAR & 256) {                                                                                  \
+            /* split wait (round-3 probe): chan-hi is read LAST and waited for behind the first 16 MFMAs, which need */ \
+            /* chan-lo + pixel-lo only; barrier 1 moves behind them too (the buffer is refilled in phase B at the earliest) */ \
+            S4_READ_B(BUF_, 0, wlo);                                                                      \
+            __builtin_amdgcn_sched_barrier(0);                                                            \
+            S4_READ_A(0, T);                                                                              \
+            __builtin_amdgcn_sched_barrier(0);                                                            \
+            S4_READ_B(BUF_, 1, whi);                                                                      \
+            asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");                                            \
+            __builtin_amdgcn_sched_barrier(0);                                                            \
+            S4_PRIO(S4_MFMA_PRIO);                                                                        \
+            S4_MFMA(0, 0, wlo);                                                                           \
+            S4_PRIO(0);                                                                                   \
+            __builtin_amdgcn_sched_barrier(0);                                                            \
+            S4_LGKM0();                                                                                   \
+            S4_KBARRIER();                                                                                \
+            if ((VAR & 4) && boundary_) S4_STAGE_WP((cc + 1) * 128, 0, 4);                                \
+            S4_PRIO(S4_MFMA_PRIO);                                                                        \
+            S4_MFMA(0, 1, whi);                                                                           \
+        } else {                                                                                          \
         S4_READ_B(BUF_, 0, wlo);                                                                          \
         S4_READ_B(BUF_, 1, whi);                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                \
@@ -227,6 +247,7 @@ __global__ __launch_bounds__(256, 2) void k_conv4w(const char *__restrict__ xb, 
         S4_PRIO(S4_MFMA_PRIO);                                                                            \
         S4_MFMA(0, 0, wlo);                                                                               \
         S4_MFMA(0, 1, whi);                                                                               \
+        }                                                                                                 \
         S4_PRIO(0);                                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                \
         if ((VAR & 6) == 6 && (T) == 0 && cc > 0) {   /* first tap of a restaged chunk: phase A read rows [0, 128) only (the */ \
@@ -462,6 +483,7 @@ static inline int launch(int n, int h, int w, const void *x, const void *wgt, co
     case 87: return launch_var<87>(n, h, w, x, wgt, bias, skip, y, st);
     case 231: return launch_var<231>(n, h, w, x, wgt, bias, skip, y, st);
     case 103: return launch_var<103>(n, h, w, x, wgt, bias, skip, y, st);
+    case 263: return launch_var<263>(n, h, w, x, wgt, bias, skip, y, st);    // 7 + split wait in phase A
 #endif
     default: return launch_var<7>(n, h, w, x, wgt, bias, skip, y, st);
     }

@@ -45,7 +45,7 @@ def main():
         outs[name] = y.clone()
     # ablation arms (variant bits >= 16: no MFMAs / no fragment reads / no weight staging / no barriers) time a kernel whose
     # results are wrong by construction
-    assert all(torch.equal(outs[arms[0][0]], o) for (name, mode), o in zip(arms, outs.values()) if mode < 32), "an arm changed the result"
+    assert all(torch.equal(outs[arms[0][0]], o) for (name, mode), o in zip(arms, outs.values()) if mode < 32 or mode >= 16 + 256), "an arm changed the result"
     for _ in range(10):
         run()
     ms = {name: 0.0 for name, _ in arms}
