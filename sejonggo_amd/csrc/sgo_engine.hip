@@ -222,7 +222,7 @@ struct Eng {
     // descent through a late-game tree spent its time on (k_search averaged 0.9 ms per call over a full 19x19 game, 0.2 ms at
     // the first plies).
     __device__ int top_one(int blk, bool f64, int &child) const {
-        const size_t sb = slot_base(blk);
+        const size_t pb = ph(blk), sb = pb * (size_t)G::APAD;
         constexpr int J = (G::APAD + 63) / 64;
         int n_[J], cb_[J];
         float p_[J], q_[J];
@@ -232,7 +232,7 @@ struct Eng {
         for (int j = 0; j < J; j++) {
             const int i = lane + 64 * j;
             const bool in = i < G::APAD;
-            const uint32_t lw = in ? c.legal[sb / G::APAD * G::NW + (i >> 5)] : 0u;
+            const uint32_t lw = in ? c.legal[pb * G::NW + (i >> 5)] : 0u;
             const int nv = in ? c.cN[sb + i] : 0;
             const int bz = in ? (int)c.cBusy[sb + i] : 1;
             p_[j] = in ? c.cP[sb + i] : 0.f;
@@ -334,7 +334,7 @@ struct Eng {
 
     // children of block `blk` from a policy row (play.py:391-421); legal[] of the block must be valid
     __device__ void expand(int blk, const float *policy, const int32_t *lut, const double *noise, double eps) const {
-        const size_t sb = slot_base(blk);
+        const size_t pb = ph(blk), sb = pb * (size_t)G::APAD;
         double *p64 = c.rootP64 + (size_t)g * G::APAD;
         // all loads of the node first (legal words, the symmetry LUT, then the gathered priors: two dependent round trips for the
         // whole node), then the stores: the slot-by-slot loop paid three dependent round trips per 64 slots -- 43 % of k_search
@@ -345,7 +345,7 @@ struct Eng {
 #pragma unroll
         for (int j = 0; j < J; j++) {
             const int i = lane + 64 * j;
-            ex[j] = i < G::APAD && legal_bit(blk, i < G::APAD ? i : 0);
+            ex[j] = i < G::APAD && ((c.legal[pb * G::NW + ((i < G::APAD ? i : 0) >> 5)] >> (i & 31)) & 1u);
             src[j] = i < G::A ? lut[i] : 0;
         }
 #pragma unroll
