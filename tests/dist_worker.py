@@ -48,6 +48,29 @@ def main():
                 and list(a["rank"]) == sorted(a["rank"])
     else:
         pipe_ok = pipe_ok and all(a is None for a in got)
+    # slots that must GROW: the last rank suddenly sends 60 tuples (33 KB: its own slot is re-allocated at stage 1, every other
+    # rank's at stage 2 when it learns the count), then everybody is small again; with the all_gather collective as well
+    for coll in ("gather", "all_gather"):
+        tg2 = TupleGather(dt, collective=coll, side_stream=False)
+        got2 = []
+        sizes = [2, 60 if rank == world - 1 else 1, 3, 1, 2]
+        for k, m in enumerate(sizes):
+            b = np.zeros(m, dtype=dt)
+            b["rank"] = rank; b["game_seq"] = 100 + k; b["move_n"] = np.arange(m)
+            b["pi"] = np.float32(rank + k)
+            got2.extend(tg2.submit(b))
+        got2.extend(tg2.flush())
+        pipe_ok = pipe_ok and len(got2) == len(sizes)
+        if rank == 0:
+            for k, a in enumerate(got2):
+                want = [(60 if (k == 1 and r == world - 1) else [2, 1, 3, 1, 2][k]) for r in range(world)]
+                pipe_ok = pipe_ok and a is not None and len(a) == sum(want) and bool((a["game_seq"] == 100 + k).all())
+                o = 0
+                for r, w in enumerate(want):
+                    part = a[o:o + w]
+                    pipe_ok = pipe_ok and bool((part["rank"] == r).all()) and list(part["move_n"]) == list(range(w)) \
+                        and bool((part["pi"] == np.float32(r + k)).all())
+                    o += w
     ident = device_identities()
     # weights: every rank starts from different values; after the broadcast all hold rank 0's
     from sejonggo_amd.net import PolicyValueNet
