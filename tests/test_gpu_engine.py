@@ -221,6 +221,36 @@ def test_headline_batch_shape_equals_the_oracle_on_sampled_slots(L):
     eng.close()
 
 
+def test_headline_batch_shape_from_the_shared_pool(L):
+    """1 024 concurrent 19x19 games whose private regions hold 10 blocks each: every round 8 192 overflow ids are backed by
+    8 192 concurrent atomic pops of ONE shared free stack (one per wavefront), every move's re-root returns thousands of blocks
+    through the return list, k_compact merges them.  Two plies; sampled slots against the oracle, pool accounting exact."""
+    from sejonggo_amd.engine import SelfPlayEngine
+    from sejonggo_amd.stub_nets import make_stub
+    S, sims, E, G, nm = 19, 400, 8, 1024, 2
+    net = make_stub("hash", S)
+    rng = np.random.RandomState(79)
+    noises = rng.dirichlet([0.03] * (S * S + 1), size=G)
+    uni = rng.random_sample((G, nm))
+    pool = G * 900
+    eng = SelfPlayEngine(net, size=S, n_games=G, sims=sims, energy=E, stop_exploration=30, num_moves=nm, komi=5.5,
+                         symmetry="identity", blocks_per_game=10, shared_blocks=pool)
+    eng.start_games(np.arange(G), noises=noises, uniforms=uni)
+    games = eng.run()
+    assert len(games) == G and eng.status.total_moves == G * nm and eng.status.none_events == 0
+    assert eng.status.total_evals == G * nm * (1 + sims)
+    _compare_with_oracle(eng, games, [0, 1, 63, 64, 500, 777, 1023], S, sims, E, 30, nm, uni, noises, net)
+    info = eng.pool_info()
+    res = eng.results()
+    held = sum(max(0, int(r["blocks_high_water"]) - 10) for r in res)         # an upper bound of what the games still hold
+    assert info["shared_blocks"] == pool and 0 < info["shared_free_low_water"] <= info["shared_free"] <= pool
+    assert pool - info["shared_free"] <= held                                 # nothing leaked: blocks out of the pool are in trees
+    eng.start_games(np.arange(G), noises=noises, uniforms=uni)                # restarts hand everything back
+    eng.step()
+    assert eng.pool_info()["shared_free"] == pool
+    eng.close()
+
+
 TWO_MODEL_FILES = ["async_09.npz", "async_10.npz", "async_11.npz"]
 
 
@@ -230,7 +260,8 @@ def _eval_engine(z, halt_at=None, **kw):
     from tests.helpers import name_of
     S, nm = int(z["size"]), int(z["num_moves"])
     kinds = name_of(z, "net").split("+")
-    eng = SelfPlayEngine(make_stub(kinds[0], S), net2=make_stub(kinds[1], S), size=S, n_games=1, sims=int(z["sims"]),
+    wrap = kw.pop("wrap", lambda net, size: net)
+    eng = SelfPlayEngine(wrap(make_stub(kinds[0], S), S), net2=wrap(make_stub(kinds[1], S), S), size=S, n_games=1, sims=int(z["sims"]),
                          energy=int(z["energy"]), stop_exploration=int(z["stop_exploration"]), num_moves=None if nm < 0 else nm,
                          komi=float(z["komi"]), symmetry="identity", **kw)
     eng.start_eval_games([0], first_model=[0 if float(z["first_draw"]) < .5 else 1])
@@ -281,15 +312,43 @@ def test_two_model_games_on_the_device_equal_the_reference(L, fn, pool):
         eng.close()
 
 
-def test_many_two_model_games_share_a_context(L):
+@pytest.mark.parametrize("fn", TWO_MODEL_FILES)
+def test_two_model_games_on_the_packed_record_route(L, fn):
+    """Two-model games with BOTH nets on the packed-record route: the rows of a mixed evaluation list are split per model by
+    gathering the device-side index list (engine._index_view over the engine's own memory) and each model's stem kernel reads
+    its rows' records through that sub-list.  Moves, values, priors and per-model evaluation counts against the reference's
+    goldens."""
+    from tests.helpers import name_of
+    z = load(fn)
+    S = int(z["size"])
+    eng = _eval_engine(z, wrap=_PackedProbe)
+    assert eng.packed and eng.two_model
+    games = eng.run()
+    gd = games[0]
+    assert len(gd["moves"]) == len(z["move_index"])
+    for i, mv in enumerate(gd["moves"]):
+        a = mv["move"][0] + S * mv["move"][1] if mv["move"][1] != S else S * S
+        assert a == z["move_index"][i] and mv["player"] == z["move_player"][i], i
+        assert mv["value"].tobytes() == z["move_value"][i].tobytes() and mv["policy"].tobytes() == z["move_policy"][i].tobytes(), i
+    assert gd["result"] == name_of(z, "result")
+    assert eng.n_model_positions == [int(z["n_predict_best"]), int(z["n_predict_latest"])]
+    eng.close()
+
+
+@pytest.mark.parametrize("packed", [False, True], ids=["tensor_route", "packed_records"])
+def test_many_two_model_games_share_a_context(L, packed):
     """32 concurrent evaluation games with both colour assignments in one context: every game equals the single-game run
-    with the same first player (games do not interact), and both nets see roughly half of the positions."""
+    with the same first player (games do not interact), and both nets see roughly half of the positions.  On the packed
+    route every mixed evaluation list is split per model by gathering the device-side index list: each net's stem kernel
+    reads its rows' records through its own sub-list."""
     from sejonggo_amd.engine import SelfPlayEngine
     from sejonggo_amd.stub_nets import make_stub
     S, sims, E, nm, G = 9, 32, 8, 12, 32
     a, b = make_stub("hash", S), make_stub("hash2", S)
     first = [g % 2 for g in range(G)]
-    eng = SelfPlayEngine(a, net2=b, size=S, n_games=G, sims=sims, energy=E, stop_exploration=0, num_moves=nm, symmetry="identity")
+    na, nb_ = (_PackedProbe(a, S), _PackedProbe(b, S)) if packed else (a, b)
+    eng = SelfPlayEngine(na, net2=nb_, size=S, n_games=G, sims=sims, energy=E, stop_exploration=0, num_moves=nm, symmetry="identity")
+    assert eng.packed == packed
     eng.start_eval_games(np.arange(G), first_model=first)
     games = {gd["slot"]: gd for gd in eng.run()}
     assert len(games) == G and sum(eng.n_model_positions) == eng.status.total_evals
