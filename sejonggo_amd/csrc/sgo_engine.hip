@@ -1102,7 +1102,9 @@ sgo_ctx *sgo_ctx_create(const sgo_config *cfg) {
     }
     if (priv < cfg->energy + 2) priv = cfg->energy + 2;
     long L = priv + pool;
-    if (L > 40L * cfg->sims + 256 && cfg->shared_blocks <= 0) L = std::max(priv, 40L * cfg->sims + 256);
+    // default id space per game: 20 sims + 128 (the most any game has needed is 12.1 sims); at 19x19 / 400 sims that keeps
+    // k_search's LDS work queue at 36 KB, i.e. four games per CU resident at once (at 40 sims: 65 KB, two per CU, +25 % per call)
+    if (L > 20L * cfg->sims + 128 && cfg->shared_blocks <= 0) L = std::max(priv, 20L * cfg->sims + 128);
     if (L > lds_max) L = std::max(priv, lds_max);
     c.cap = (int)priv;
     c.L = (int)L;
