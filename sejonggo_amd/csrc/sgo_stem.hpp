@@ -1,6 +1,6 @@
 // sgo_stem.hpp -- hand-written MFMA kernel for the STEM convolution of the resident policy/value net: 3x3, 'valid'
 // (model.py:58-59 of the reference omits `padding`, so the 19x19 board becomes a 17x17 tower), 17 input planes presented as
-// 32 fp16 channels (the network-input row written by k_board_advance_rows_nn / k_nn_pack, channels 17..31 zero) -> 256
+// 32 fp16 channels (the network-input row written by k_nn_pack, layout 2: channels 17..31 zero) -> 256
 // channels, bias (BatchNorm folded) + ReLU fused.  NHWC fp16 in / out, weights [256][3][3][32] fp16, fp32 accumulate.
 // gfx950 only.
 //
