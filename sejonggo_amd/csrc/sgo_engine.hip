@@ -49,6 +49,7 @@ struct GameState {
     int32_t i_uniform, n_uniform;
     int32_t noise_used, game_seq, n_req, req_kind;
     int32_t eval_base, root_requested, winner, black;
+    int32_t list_base, pad2_;              // k_compact: base of the game's requests in the leaf list (or among the root requests)
     double white;
     int32_t n_moves, last_player;
     int64_t n_predict, none_events;
@@ -108,8 +109,6 @@ struct Ctx {
     // compacted lists
     int32_t *evalIdx, *leafIn, *leafMv, *leafOut;  // [G*E]
     int32_t *evalModel;   // [G*E] which model evaluates each row of the evaluation list (two-model games; 0 otherwise)
-    int32_t *leafRow;     // [G*E] row of each leaf in the evaluation list (fused board_advance + nn_input_pack)
-    int32_t *rootIdx, *rootRow;  // [G] block id / evaluation row of this step's root requests
     // records
     sgo_move_record *recs;
     uint32_t *recPacked;
@@ -816,10 +815,20 @@ __global__ __launch_bounds__(64) void k_search(Ctx c, const float *policy, const
 // ---------------------------------------------------------------------------------------- k_compact
 // One block.  Exclusive prefix sums of the per-game request counts -> dense evaluation list (block ids
 // in game-major order) and dense leaf list for board_advance; also folds the status words.
+// The six block-wide scans (evaluation / leaf / root counts, active, done, first failing game) run as wave-level shuffles
+// + one pass over the 16 wave totals: two block barriers instead of the twenty of a Hillis-Steele scan over LDS arrays.
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_up(v, o);
+        if (lane >= o) v += u;
+    }
+    return v;
+}
 __global__ __launch_bounds__(1024) void k_compact(Ctx c) {
-    __shared__ int sE[1024], sL[1024], sR[1024];
-    __shared__ int sAct[1024], sDone[1024], sErr[1024];
-    const int t = threadIdx.x;
+    __shared__ int wE[16], wL[16], wR[16], wAct[16], wDone[16], wErr[16];
+    __shared__ int tot[6];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int per = (c.G + 1023) / 1024;
     const int g0 = t * per, g1 = min(c.G, g0 + per);
     int ne = 0, nl = 0, nr = 0, act = 0, done = 0, err = 0x7fffffff;
@@ -832,37 +841,61 @@ __global__ __launch_bounds__(1024) void k_compact(Ctx c) {
         if (s.phase == PH_DONE) done++;
         if (s.error && err == 0x7fffffff) err = g;
     }
-    sE[t] = ne; sL[t] = nl; sR[t] = nr; sAct[t] = act; sDone[t] = done; sErr[t] = err;
-    __syncthreads();
-    // Hillis-Steele inclusive scan
-    for (int o = 1; o < 1024; o <<= 1) {
-        int ve = (t >= o) ? sE[t - o] : 0, vl = (t >= o) ? sL[t - o] : 0, vq = (t >= o) ? sR[t - o] : 0;
-        int va = (t >= o) ? sAct[t - o] : 0, vd = (t >= o) ? sDone[t - o] : 0;
-        int vr = (t >= o) ? sErr[t - o] : 0x7fffffff;
-        __syncthreads();
-        sE[t] += ve; sL[t] += vl; sR[t] += vq; sAct[t] += va; sDone[t] += vd; sErr[t] = min(sErr[t], vr);
-        __syncthreads();
+    // inclusive scans inside the wave
+    int iE = wave_incl_scan(ne, lane), iL = wave_incl_scan(nl, lane), iR = wave_incl_scan(nr, lane);
+    int sAct = act, sDone = done, sErr = err;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        sAct += __shfl_xor(sAct, o);
+        sDone += __shfl_xor(sDone, o);
+        sErr = min(sErr, __shfl_xor(sErr, o));
     }
-    int be = sE[t] - ne, bl = sL[t] - nl, br = sR[t] - nr;
+    if (lane == 63) { wE[w] = iE; wL[w] = iL; wR[w] = iR; }
+    if (lane == 0) { wAct[w] = sAct; wDone[w] = sDone; wErr[w] = sErr; }
+    __syncthreads();
+    if (w == 0) {
+        // exclusive scan of the 16 wave totals (lanes 0..15), totals of everything in tot[]
+        const int vE = lane < 16 ? wE[lane] : 0, vL = lane < 16 ? wL[lane] : 0, vR = lane < 16 ? wR[lane] : 0;
+        const int xE = wave_incl_scan(vE, lane), xL = wave_incl_scan(vL, lane), xR = wave_incl_scan(vR, lane);
+        int a = lane < 16 ? wAct[lane] : 0, d = lane < 16 ? wDone[lane] : 0, e = lane < 16 ? wErr[lane] : 0x7fffffff;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            a += __shfl_xor(a, o);
+            d += __shfl_xor(d, o);
+            e = min(e, __shfl_xor(e, o));
+        }
+        if (lane < 16) { wE[lane] = xE - vE; wL[lane] = xL - vL; wR[lane] = xR - vR; }
+        if (lane == 15) { tot[0] = xE; tot[1] = xL; tot[2] = xR; }
+        if (lane == 0) { tot[3] = a; tot[4] = d; tot[5] = e; }
+    }
+    __syncthreads();
+    // phase 1: every game's bases (thread t owns games [g0, g1))
+    int be = wE[w] + iE - ne, bl = wL[w] + iL - nl, br = wR[w] + iR - nr;
     for (int g = g0; g < g1; g++) {
         GameState &s = c.gs[g];
         s.eval_base = be;
-        for (int j = 0; j < s.n_req; j++) {
-            c.evalIdx[be + j] = c.reqBlk[(size_t)g * c.E + j];
-            c.evalModel[be + j] = s.cur_model;
-            if (s.req_kind == 1) {
-                c.leafIn[bl + j] = c.reqParent[(size_t)g * c.E + j];
-                c.leafMv[bl + j] = c.reqMove[(size_t)g * c.E + j];
-                c.leafOut[bl + j] = c.reqBlk[(size_t)g * c.E + j];
-                c.leafRow[bl + j] = be + j;
-            } else {
-                c.rootIdx[br + j] = c.reqBlk[(size_t)g * c.E + j];
-                c.rootRow[br + j] = be + j;
-            }
-        }
+        s.list_base = (s.req_kind == 1) ? bl : br;
         be += s.n_req;
         if (s.req_kind == 1) bl += s.n_req;
         else br += s.n_req;
+    }
+    __syncthreads();
+    // phase 2: one (game, request) pair per thread and pass -- all loads of a pair are independent of every other pair's, so
+    // the 8 192 pairs of a 1 024-game step are a few memory round trips instead of eight dependent ones per game
+    const int pairs = c.G * c.E;
+    for (int e = t; e < pairs; e += 1024) {
+        const int g = e / c.E, j = e - g * c.E;
+        const GameState &s = c.gs[g];
+        if (j >= s.n_req) continue;
+        const int row = s.eval_base + j, blk = c.reqBlk[e];
+        c.evalIdx[row] = blk;
+        c.evalModel[row] = s.cur_model;
+        if (s.req_kind == 1) {
+            const int li = s.list_base + j;
+            c.leafIn[li] = c.reqParent[e];
+            c.leafMv[li] = c.reqMove[e];
+            c.leafOut[li] = blk;
+        }
     }
     // shared blocks released during this step's k_search (and by k_start since the previous step) go back on the free stack
     // here, between two k_search launches: pops and pushes never run concurrently
@@ -874,12 +907,12 @@ __global__ __launch_bounds__(1024) void k_compact(Ctx c) {
     }
     if (t == 1023) {
         DevStatus d;
-        d.n_eval = sE[1023]; d.n_leaf = sL[1023]; d.n_records = c.counters->rec_count;
-        d.n_active = sAct[1023]; d.n_done = sDone[1023];
-        int eg = sErr[1023];
+        d.n_eval = tot[0]; d.n_leaf = tot[1]; d.n_records = c.counters->rec_count;
+        d.n_active = tot[3]; d.n_done = tot[4];
+        int eg = tot[5];
         d.error_game = (eg == 0x7fffffff) ? -1 : eg;
         d.error = (eg == 0x7fffffff) ? 0 : c.gs[eg].error;
-        d.n_root = sR[1023];
+        d.n_root = tot[2];
         d.total_moves = c.counters->total_moves; d.total_evals = c.counters->total_evals;
         d.none_events = c.counters->none_events;
         *c.dstatus = d;
@@ -1026,10 +1059,7 @@ static int ctx_alloc(Ctx &c) {
     CK(dalloc(&c.leafIn, nr));
     CK(dalloc(&c.leafMv, nr));
     CK(dalloc(&c.leafOut, nr));
-    CK(dalloc(&c.leafRow, nr));
     CK(dalloc(&c.evalModel, nr));
-    CK(dalloc(&c.rootIdx, nr));
-    CK(dalloc(&c.rootRow, nr));
     CK(dalloc(&c.recs, (size_t)c.rec_cap));
     CK(dalloc(&c.recPacked, (size_t)c.rec_cap * c.RW));
     CK(dalloc(&c.recPolicy, (size_t)c.rec_cap * c.A));
@@ -1051,7 +1081,7 @@ static int ctx_alloc(Ctx &c) {
 static void ctx_free(Ctx &c) {
     void *ptrs[] = {c.gs, c.pos, c.legal, c.cP, c.cW, c.cQ, c.cN, c.cB, c.cBusy, c.bParent, c.bSlot, c.freeList, c.ovfMap, c.poolFree, c.poolRet, c.poolCtl,
                     c.rootP64, c.noise, c.uniforms, c.fParent, c.fSlot, c.fBlk, c.fEvalLocal, c.fEvaluated, c.fValue,
-                    c.reqBlk, c.reqParent, c.reqMove, c.evalIdx, c.leafIn, c.leafMv, c.leafOut, c.leafRow, c.evalModel, c.rootIdx, c.rootRow, c.recs, c.recPacked,
+                    c.reqBlk, c.reqParent, c.reqMove, c.evalIdx, c.leafIn, c.leafMv, c.leafOut, c.evalModel, c.recs, c.recPacked,
                     c.recPolicy, c.counters, c.dstatus, c.symLut, c.stage};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
