@@ -26,7 +26,7 @@ extern "C" long sgo_conv_tower_slice_cap(long cap) {
 
 extern "C" int sgo_conv_tower_kernel(int mode) {
     const int old = g_tower_kernel;
-    if (mode == 0 || mode == 1 || (mode >= 16 && mode < 16 + 1024)) g_tower_kernel = mode;   // 16 + v: k_conv4w schedule variant v (A/B builds)
+    if (mode == 0 || mode == 1 || (mode >= 16 && mode < 16 + 4096)) g_tower_kernel = mode;   // 16 + v: k_conv4w schedule variant v (A/B builds)
     return old;
 }
 

@@ -99,6 +99,12 @@ __global__ __launch_bounds__(256, 2) void k_conv4w(const char *__restrict__ xb, 
     }
     const int HW = H * W, HALO = W + 1, NROWS = 256 + 2 * HALO;
     const char *wbh = wb + (size_t)chalf * CT * WROWB;     // this half's 128 filters
+    if (VAR & 512) {
+        // stagger probe (round 3): the two workgroups that share a CU start together and take the same time per tile, so their
+        // prologues / epilogues (no MFMAs) coincide; hold the second slot's first workgroup back by about half a tile
+        if (blockIdx.x < 512 && ((blockIdx.x >> 8) & 1))
+            for (int i_ = 0; i_ < (VAR & 1024 ? 3 : 6); i_++) __builtin_amdgcn_s_sleep(127);
+    }
 
     if (tid < LZ_BYTES / 16) *reinterpret_cast<intx4 *>(smem + LZ + tid * 16) = intx4{0, 0, 0, 0};
     if (tid + 256 < LZ_BYTES / 16) *reinterpret_cast<intx4 *>(smem + LZ + (tid + 256) * 16) = intx4{0, 0, 0, 0};
@@ -484,6 +490,8 @@ static inline int launch(int n, int h, int w, const void *x, const void *wgt, co
     case 231: return launch_var<231>(n, h, w, x, wgt, bias, skip, y, st);
     case 103: return launch_var<103>(n, h, w, x, wgt, bias, skip, y, st);
     case 263: return launch_var<263>(n, h, w, x, wgt, bias, skip, y, st);    // 7 + split wait in phase A
+    case 519: return launch_var<519>(n, h, w, x, wgt, bias, skip, y, st);    // 7 + half-tile stagger of the CU's second slot
+    case 1543: return launch_var<1543>(n, h, w, x, wgt, bias, skip, y, st);  // 7 + quarter-tile stagger
 #endif
     default: return launch_var<7>(n, h, w, x, wgt, bias, skip, y, st);
     }
