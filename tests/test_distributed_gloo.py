@@ -57,6 +57,12 @@ def test_gather_and_broadcast_world2(tmp_path):
     _check(_launch(2, tmp_path), 2)
 
 
+def test_gather_and_broadcast_world4(tmp_path):
+    """Four ranks (half of the node the driver scales to): ragged gathers incl. slot growth on every non-sending rank, the
+    pipelined submit order, device identities of four ranks, weights from rank 0."""
+    _check(_launch(4, tmp_path), 4)
+
+
 def test_gather_and_broadcast_world1_runs_the_collectives(tmp_path):
     """A one-rank process group still goes through all_gather / gather / broadcast (no early return)."""
     _check(_launch(1, tmp_path), 1)
