@@ -37,7 +37,7 @@ conf = {
     'GAMES_PER_GPU': 1024,       # concurrent game slots resident on one MI355X
     'NET_DTYPE': 'fp16',
     'SYMMETRY_MODE': 'random1',  # 'random1' = reference behaviour (symmetry.py:127-132); 'avg8' = 8-fold averaging
-    'ENGINE_HALVES': 1,          # 2: two half-populations alternating on two HIP streams (engine.DualEngine), captured rounds
+    'ENGINE_HALVES': 0,          # 2: two half-populations alternating on two HIP streams (engine.DualEngine), captured rounds; 1: one population; 0: by round size
     'ENGINE_GRAPH': False,       # every engine round one captured launch chain (hipGraph): for launch-bound configurations
     'BLOCKS_PER_GAME': 0,        # PRIVATE tree blocks per resident game; 0 = the engine's default (8 * sims + 128)
     'SHARED_BLOCKS': 0,          # tree blocks shared by all games of a GPU; 0 = default (2 * sims per game) unless BLOCKS_PER_GAME is set, < 0 = default

@@ -109,7 +109,13 @@ def run_selfplay(gpu_id, model_indicator="BEST_SYM", n_games=None, games_per_gpu
     # conf['ENGINE_HALVES'] = 2: two half-populations alternating on two streams, every round a captured launch chain
     # (engine.DualEngine); conf['ENGINE_GRAPH']: captured rounds on one population.  Both pay on small boards / shallow nets,
     # where a round is launch-bound; at 19x19 with the 20-block net a round is one 85-ms tower and neither matters.
-    if int(conf.get('ENGINE_HALVES', 1) or 1) == 2 and kw['n_games'] >= 2:
+    halves = int(conf.get('ENGINE_HALVES', 0) or 0)
+    if halves == 0:
+        # auto: the two-stream form pays where a round is short (the tower's launch does not fill the chip for long): below
+        # ~400 000 leaf pixels per round (9x9 / 256 games: 100 000; 19x19 / 1 024 games: 2.4 million)
+        t = max(1, kw['size'] - 2)
+        halves = 2 if (getattr(net, "packed_ok", False) and kw['n_games'] >= 2 and kw['n_games'] * kw['energy'] * t * t < 400000) else 1
+    if halves == 2 and kw['n_games'] >= 2:
         from .engine import DualEngine
         eng = DualEngine(net, **kw)
     else:
