@@ -489,7 +489,10 @@ def run_rank(args):
                          "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": None, "algorithmic_bytes_per_position": per_leaf,
                          "network_input": "none: the stem reads the packed records (%s)" % ("sgo_stem_packed_dev" if getattr(eng, "packed", False) else "tensor route: k_nn_pack"),
-                         "positions_per_launch": per_launch, "avg_launch_ms": avg_ms, "launches": adv_n},
+                         "positions_per_launch": per_launch, "avg_launch_ms": avg_ms, "launches": adv_n,
+                         "note": "one launch per search round carries games x energy leaves: %d x 1 834 B = %.1f MB, 1.9 us at the HBM peak -- the figure is "
+                                 "the floor of one small launch (dependent load -> compute -> store of 4 096 wavefronts), not a bandwidth limit; the same "
+                                 "kernel family on a chip-filling batch is roofline_saturated" % (int(per_launch), per_launch * per_leaf / 1e6)},
             "net": {"evals": int(evals), "flops_per_eval": flops,
                     "achieved_tflops": (evals * sym_mult * flops / dt / 1e12) if flops else None,
                     "peak_tflops": 2500.0, "bound": "mfma"},
