@@ -132,6 +132,8 @@ class SelfPlayEngine(object):
         self._pol_static = self._val_static = self._kdev = None
         self._in_flight = False
         self.n_graph_replays = 0
+        self._done_ev = None
+        self.round_timeout_s = float(conf.get('ROUND_TIMEOUT_S', 300.0))
 
     def close(self):
         if getattr(self, "ctx", None):
@@ -284,7 +286,9 @@ class SelfPlayEngine(object):
             self._pol_static = torch.zeros((self.G * self.E, self.A), dtype=torch.float32, device=self.device)
             self._val_static = torch.zeros((self.G * self.E,), dtype=torch.float32, device=self.device)
             self._graph_pool = torch.cuda.graph_pool_handle()
-            self._cap_stream = torch.cuda.Stream(device=self.device)
+            # capture on the engine's own stream where it has one: every extra HIP stream is another candidate for sharing a
+            # hardware queue with the stepping streams (see sejonggo_amd/__init__.py on GPU_MAX_HW_QUEUES)
+            self._cap_stream = self.stream if self.stream is not None else torch.cuda.Stream(device=self.device)
         kd = self._kdev.data_ptr()
         # library handles / workspaces of this batch size come into being outside the capture
         self.net.predict_packed(self._rec_ptr, self._idx_ptr, nb, 0, kd)
@@ -317,12 +321,24 @@ class SelfPlayEngine(object):
             self.n_net_positions += n
             g.replay()
             self.n_graph_replays += 1
+            if self._done_ev is None:
+                self._done_ev = self.torch.cuda.Event()
+            self._done_ev.record()
         self._in_flight = True
 
     def finish(self):
         """Second half: wait for the queued round, read what it reported."""
         if self._in_flight:
-            (self.stream or self.torch.cuda.current_stream()).synchronize()
+            # wait by polling the round's event, with a deadline: a round that never completes becomes an error the caller
+            # sees, not a process that sits in hipStreamSynchronize for ever (see DualEngine.MAX_ROUND_PIXELS)
+            import time
+            ev, t0 = self._done_ev, time.perf_counter()
+            while not ev.query():
+                dt = time.perf_counter() - t0
+                if dt > 2e-3:
+                    time.sleep(5e-5)
+                if dt > self.round_timeout_s:
+                    raise _lib.SgoError("a captured round did not complete within %.0f s (stream stalled)" % self.round_timeout_s)
             _lib.check(self.lib.sgo_step_status(self.ctx, C.byref(self.status)), "sgo_step_status")
             self._in_flight = False
             self.n_steps += 1
@@ -559,11 +575,23 @@ class DualEngine(object):
     state machines: a game's moves, trees and records are what the single-context engine produces for the same draws.
     Same surface as SelfPlayEngine for the drivers (start_games / step / drain / results / game_data / records / status)."""
 
-    def __init__(self, net, n_games=None, seed=0, device=0, **kw):
+    # Largest round (leaf pixels = games x energy x tower points) the two-stream form is allowed at.  With LONG kernels on both
+    # streams (tower launches of >= ~0.5 ms: 19x19 with >= 512 games) the run stalls intermittently after a few captured
+    # rounds -- the GPU stays responsive, no kernel of ours waits on another, 4 or 8 hardware queues alike
+    # (tools/debug_dual.py dual 19 512 20 400 60; gpurun_out/r03ae..ah); with the short kernels of small boards it has run tens
+    # of thousands of rounds.  Until that is understood the form is refused where it has nothing to gain anyway (a 19x19 round
+    # is one 40-85 ms tower pass: 21.9 ms per round with either engine at 256 games).
+    MAX_ROUND_PIXELS = 400000
+
+    def __init__(self, net, n_games=None, seed=0, device=0, allow_large=False, **kw):
         import torch
         G = n_games or conf['GAMES_PER_GPU']
         if G < 2:
             raise ValueError("DualEngine needs at least two games")
+        S_, E_ = kw.get('size') or conf['SIZE'], kw.get('energy') or conf['ENERGY']
+        if not allow_large and G * E_ * (S_ - 2) * (S_ - 2) >= self.MAX_ROUND_PIXELS:
+            raise ValueError("DualEngine: a round of %d x %d leaves on a %dx%d board is too large for the two-stream form (see "
+                             "DualEngine.MAX_ROUND_PIXELS); use SelfPlayEngine" % (G, E_, S_, S_))
         kw.pop("stream", None)
         kw.setdefault("graph", True)
         sizes = [G - G // 2, G // 2]

@@ -112,12 +112,13 @@ def run_selfplay(gpu_id, model_indicator="BEST_SYM", n_games=None, games_per_gpu
     halves = int(conf.get('ENGINE_HALVES', 0) or 0)
     if halves == 0:
         # auto: the two-stream form pays where a round is short (the tower's launch does not fill the chip for long): below
-        # ~400 000 leaf pixels per round (9x9 / 256 games: 100 000; 19x19 / 1 024 games: 2.4 million)
+        # 200 000 leaf pixels per round (9x9 / 256 games: 100 000; 19x19 / 1 024 games: 2.4 million), and is refused above
+        # DualEngine.MAX_ROUND_PIXELS, where long kernels on two streams have stalled the run
         t = max(1, kw['size'] - 2)
-        halves = 2 if (getattr(net, "packed_ok", False) and kw['n_games'] >= 2 and kw['n_games'] * kw['energy'] * t * t < 400000) else 1
+        halves = 2 if (getattr(net, "packed_ok", False) and kw['n_games'] >= 2 and kw['n_games'] * kw['energy'] * t * t < 200000) else 1
     if halves == 2 and kw['n_games'] >= 2:
         from .engine import DualEngine
-        eng = DualEngine(net, **kw)
+        eng = DualEngine(net, **kw)            # refuses large rounds (DualEngine.MAX_ROUND_PIXELS): an explicit setting fails loudly
     else:
         eng = SelfPlayEngine(net, graph=bool(conf.get('ENGINE_GRAPH', False)), **kw)
     slot_game, slot_resign = {}, {}

@@ -3,11 +3,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from sejonggo_amd.engine import DualEngine, SelfPlayEngine
 from sejonggo_amd.net import build_fused_net
+from sejonggo_amd.conf import conf
+conf['ROUND_TIMEOUT_S'] = float(os.environ.get('SGO_ROUND_TIMEOUT_S', '20'))
 mode = sys.argv[1]
 S, G = int(sys.argv[2]), int(sys.argv[3]); blocks = int(sys.argv[4]); sims = int(sys.argv[5])
 net, _ = build_fused_net(S, blocks, 256, name="dbg", seed=0)
 kw = dict(n_games=G, size=S, sims=sims, energy=8, stop_exploration=30, symmetry=sys.argv[7] if len(sys.argv) > 7 else "random1", seed=1, raise_on_error=False)
-eng = DualEngine(net, **kw) if mode == "dual" else SelfPlayEngine(net, graph=(mode == "graph"), **kw)
+eng = DualEngine(net, allow_large=True, **kw) if mode == "dual" else SelfPlayEngine(net, graph=(mode == "graph"), **kw)
 eng.start_games(np.arange(G))
 t0 = time.time()
 for i in range(int(sys.argv[6])):
