@@ -125,7 +125,7 @@ def main():
     dt = time.time() - t0
     print("host seconds: stepping %.1f, turnover %.1f, waiting for writers at the end %.1f" % (
         stats.get("step", 0), stats.get("turnover", 0), stats.get("writer_wait", 0)))
-    print("engine steps %d; slots that failed and were discarded: %d of %d started" % (
+    print("engine steps %d; games started but not written (failed slots, and zero-move resignations when resigning is on): %d of %d" % (
         stats.get("steps", -1), a.games - played if a.games >= played else 0, a.games))
     lens = np.array(lens)
     print("played %d games in %.1f s: %d positions, %.1f positions/s; length min/mean/max %d/%.1f/%d" % (
