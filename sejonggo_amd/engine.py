@@ -633,6 +633,15 @@ class DualEngine(object):
             for e in self.halves:
                 e.launch()
             self._started = True
+        import os
+        if os.environ.get("SGO_DUAL_SERIAL") == "1":      # diagnostic: the halves' rounds strictly one after the other
+            for e in self.halves:
+                e.finish()
+            for e in self.halves:
+                e.launch()
+                e.finish()
+                e._in_flight = False
+            return self._sum_status()
         for e in self.halves:
             e.finish()
             e.launch()
