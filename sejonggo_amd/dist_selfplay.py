@@ -202,7 +202,9 @@ def main(argv=None):
             env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
             return launch_ranks(["-m", "sejonggo_amd.dist_selfplay"] + list(sys.argv[1:] if argv is None else argv), a.gpus, env=env)
     played, written = run_rank(a.backend, a.sync_every, a.max_steps)
-    print("rank %s: %d games played%s" % (os.environ.get("RANK"), played, "" if written is None else ", %d positions written" % written))
+    # one write, flushed: the ranks share the launcher's stdout
+    sys.stdout.write("rank %s: %d games played%s\n" % (os.environ.get("RANK"), played, "" if written is None else ", %d positions written" % written))
+    sys.stdout.flush()
     return 0
 
 

@@ -526,6 +526,18 @@ def test_two_half_populations_on_two_streams_equal_the_oracle(L):
     eng.close()
 
 
+def test_two_stream_engine_refuses_large_rounds(L):
+    """engine.DualEngine is for short rounds: above MAX_ROUND_PIXELS leaf pixels per round it is refused at construction (long
+    kernels on two streams have stalled captured rounds: DESIGN.md section 5), before any context is allocated."""
+    from sejonggo_amd.engine import DualEngine
+    from sejonggo_amd.stub_nets import make_stub
+    with pytest.raises(ValueError):
+        DualEngine(make_stub("hash", 19), n_games=1024, size=19, sims=400, energy=8)
+    with pytest.raises(ValueError):
+        DualEngine(make_stub("hash", 19), n_games=1)
+    assert 256 * 8 * 49 < DualEngine.MAX_ROUND_PIXELS < 512 * 8 * 289          # config 2 inside, 19x19 / 512 games outside
+
+
 @pytest.mark.parametrize("packed", [False, True])
 @pytest.mark.parametrize("mode", [1, 2, 3, 4, 5, 6, 7, "avg8"])
 def test_symmetry_modes_equal_the_oracle(L, mode, packed):
