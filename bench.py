@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--symmetry", default="random1", choices=["random1", "avg8", "identity"])
     ap.add_argument("--net", default="resnet", choices=["resnet", "uniform", "hash"])
     ap.add_argument("--split-streams", type=int, default=0, help="evaluate the net as two half batches on two streams")
-    ap.add_argument("--tower-kernel", type=int, default=-1, help="0: k_conv8w, 1: k_conv4w, -1: the library's default")
+    ap.add_argument("--tower-kernel", type=int, default=-1, help="0: k_conv8w, 1: k_conv4w, 2: k_conv4r (filter banks in fragment order, weights L2 -> registers), -1: the library's default")
     ap.add_argument("--tail-split", type=int, default=0, help="0: evaluate every batch as one launch chain (A/B of net.FusedInferenceNet._tail_split)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearse the N>1 path on fewer GPUs than ranks (ranks share devices, CPU tensors in the collectives)")
@@ -338,7 +338,7 @@ def run_rank(args):
     from sejonggo_amd.stub_nets import make_stub
     from sejonggo_amd.distributed import tuple_dtype, TupleGather, device_identities
     S, G, sims, E = args.size, args.games, args.sims, args.energy
-    if args.tower_kernel >= 0:
+    if args.tower_kernel in (0, 1):
         from sejonggo_amd import _lib as _L
         _L.load().sgo_conv_tower_kernel(args.tower_kernel)
     if args.net == "resnet":
@@ -348,6 +348,8 @@ def run_rank(args):
             net, _ = build_fused_net(S, args.blocks, args.channels, name="bench_%db" % args.blocks, seed=0, device="cuda")
             net.split_streams = bool(args.split_streams)
             net.tail_split = bool(args.tail_split)
+            if args.tower_kernel == 2:
+                net.use_packed_tower(True)
     else:
         net = make_stub(args.net, S)
     # replicas take their weights from rank 0 (one RCCL broadcast), checked identical by checksum
@@ -503,7 +505,8 @@ def run_rank(args):
             ach = conv_fl / (conv_ms * 1e-3) / 1e12
             from sejonggo_amd import _lib as _L2
             tk = _L2.load().sgo_conv_tower_kernel(-1)      # -1 leaves the selection as it is and returns it
-            kname = ("sgo_conv8w::k_conv8w (one 512-thread workgroup per CU; csrc/sgo_conv8w.hpp)" if tk == 0 else
+            kname = ("sgo_conv4r::k_conv4r (two 256-thread workgroups per CU, weights L2 -> registers; csrc/sgo_conv4r.hpp)" if getattr(net, "packed_tower", False) else
+                     "sgo_conv8w::k_conv8w (one 512-thread workgroup per CU; csrc/sgo_conv8w.hpp)" if tk == 0 else
                      "sgo_conv4w::k_conv4w (two 256-thread workgroups per CU; csrc/sgo_conv4w.hpp)")
             out["roofline"] = {"bound": "mfma", "kernel": kname + ": tower 3x3 convolution 256->256 + bias (+ skip) + ReLU, fp16 in / fp32 accumulate",
                                "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": None,
@@ -516,7 +519,7 @@ def run_rank(args):
                                               "note": "8 192 positions = 9 248 tiles = 36.1 rounds of 256 workgroups; the 29 positions "
                                                       "beyond 36 whole rounds run on a side stream inside the main launches' wall time"}}
             pc = os.path.join(ROOT, "profiles", "r03_pmc_conv.json")
-            if os.path.isfile(pc) and (S, G, E) == (19, 1024, 8):
+            if os.path.isfile(pc) and (S, G, E) == (19, 1024, 8) and not getattr(net, "packed_tower", False) and tk != 0:
                 try:   # HBM bytes per 8192-batch launch: separate --pmc passes; FETCH_SIZE doubled (gfx950 wide-read correction)
                     j = json.load(open(pc))
                     out["roofline"]["traffic"] = (2 * j["FETCH_SIZE"]["mean"] + j["WRITE_SIZE"]["mean"]) * 1024

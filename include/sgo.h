@@ -130,6 +130,17 @@ int sgo_conv3x3_bias_act_dev(int n, int h, int w, int c, int k, int pad, const v
 /* The hand-written CDNA4 kernel for the tower shape (c = k = 256, pad 1, w <= 19; csrc/sgo_conv4w.hpp, sgo_conv8w.hpp).  Same layouts. */
 int sgo_conv3x3_tower_dev(int n, int h, int w, const void *d_x, const void *d_w, const void *d_bias, const void *d_skip,
                           void *d_y, void *stream);
+/* The same convolution fed from a filter bank in MFMA-FRAGMENT ORDER (csrc/sgo_conv4r.hpp, k_conv4r: the weights go L2 -> registers,
+ * one 1-KB contiguous load per fragment, and never touch the LDS; the resident net's route since round 3).  A bank is
+ * sgo_conv3x3_tower_packed_bytes() bytes, 16-byte aligned, and is written ONCE per layer from the OHWI weights d_w
+ * [256][3][3][256] fp16 by sgo_conv3x3_tower_prepack_dev (again after every weight update); x / bias / skip / y as above.
+ * Results equal sgo_conv3x3_tower_dev's bit for bit (same MFMA order per output). */
+long sgo_conv3x3_tower_packed_bytes(void);
+int sgo_conv3x3_tower_prepack_dev(const void *d_w, void *d_wp, void *stream);
+int sgo_conv3x3_tower_packed_dev(int n, int h, int w, const void *d_x, const void *d_wp, const void *d_bias, const void *d_skip,
+                                 void *d_y, void *stream);
+/* Schedule variant of k_conv4r (A/B builds with -DSGO_CONV4W_VARIANTS; 1 = the product).  Returns the previous one; negative = query. */
+int sgo_conv_packed_variant(int v);
 /* The hand-written CDNA4 kernel for the stem (c = 32: the 17 input planes zero-padded, k = 256, pad 0, no skip;
  * csrc/sgo_stem.hpp; model.py:57-60).  x [n][h][w][32] is layout 2 of sgo_nn_pack_dev: the route of callers that hold board
  * TENSORS (put_predict_request); the self-play engine feeds the net through sgo_stem_packed_dev below instead. */

@@ -21,7 +21,7 @@ SYMBOLS = [
     "sgo_last_error", "sgo_version", "sgo_device_count", "sgo_set_device", "sgo_plane_words", "sgo_packed_words",
     "sgo_apad", "sgo_game_init", "sgo_make_play", "sgo_take_stones", "sgo_board_query", "sgo_legal_moves", "sgo_get_winner", "sgo_sym_apply",
     "sgo_sym_invert_policy", "sgo_sym_lut", "sgo_pack_dev", "sgo_unpack_dev", "sgo_advance_legal_dev",
-    "sgo_legal_dev", "sgo_score_dev", "sgo_nn_pack_dev", "sgo_bias_act_dev", "sgo_conv3x3_bias_act_dev", "sgo_conv3x3_tower_dev", "sgo_conv3x3_stem_dev", "sgo_conv_tile_order", "sgo_conv_tower_kernel", "sgo_conv_tower_slice_cap", "sgo_advance_mode", "sgo_debug_counters", "sgo_ctx_create", "sgo_ctx_destroy", "sgo_blocks_per_game", "sgo_pool_info", "sgo_start_games", "sgo_start_games2", "sgo_eval_models",
+    "sgo_legal_dev", "sgo_score_dev", "sgo_nn_pack_dev", "sgo_bias_act_dev", "sgo_conv3x3_bias_act_dev", "sgo_conv3x3_tower_dev", "sgo_conv3x3_tower_packed_bytes", "sgo_conv3x3_tower_prepack_dev", "sgo_conv3x3_tower_packed_dev", "sgo_conv_packed_variant", "sgo_conv3x3_stem_dev", "sgo_conv_tile_order", "sgo_conv_tower_kernel", "sgo_conv_tower_slice_cap", "sgo_advance_mode", "sgo_debug_counters", "sgo_ctx_create", "sgo_ctx_destroy", "sgo_blocks_per_game", "sgo_pool_info", "sgo_start_games", "sgo_start_games2", "sgo_eval_models",
     "sgo_step", "sgo_step_enqueue", "sgo_step_status", "sgo_eval_list", "sgo_stem_packed_dev", "sgo_collect", "sgo_drain_records", "sgo_game_results", "sgo_root_table", "sgo_tree_serialize", "sgo_tree_dump",
     "sgo_game_board", "sgo_set_halt", "sgo_advance_timing",
 ]
@@ -90,6 +90,10 @@ def load():
     lib.sgo_tree_dump.restype = C.c_int64
     lib.sgo_conv3x3_bias_act_dev.argtypes = [C.c_int] * 6 + [C.c_void_p] * 6
     lib.sgo_conv3x3_tower_dev.argtypes = [C.c_int] * 3 + [C.c_void_p] * 6
+    lib.sgo_conv3x3_tower_packed_dev.argtypes = [C.c_int] * 3 + [C.c_void_p] * 6
+    lib.sgo_conv3x3_tower_prepack_dev.argtypes = [C.c_void_p] * 3
+    lib.sgo_conv3x3_tower_packed_bytes.restype = C.c_long
+    lib.sgo_conv_packed_variant.argtypes = [C.c_int]
     lib.sgo_conv3x3_stem_dev.argtypes = [C.c_int] * 3 + [C.c_void_p] * 5
     lib.sgo_stem_packed_dev.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p]

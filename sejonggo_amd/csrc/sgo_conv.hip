@@ -10,11 +10,13 @@
 #include "sgo_common.hpp"
 #include "sgo_conv8w.hpp"
 #include "sgo_conv4w.hpp"
+#include "sgo_conv4r.hpp"
 #include "sgo_stem.hpp"
 #include "sgo_stem_packed.hpp"
 
 namespace {
 int g_tower_kernel = 1;       // 1: k_conv4w (two 256-thread workgroups per CU; default, +2-3 %), 0: k_conv8w (one 512-thread workgroup per CU)
+int g_packed_variant = 1;     // schedule variant of k_conv4r (A/B builds; 1 = product)
 long g_tower_slice_cap = 0;   // > 0: samples per launch of the tower kernel are capped (tests of the slice loop)
 }
 
@@ -36,15 +38,18 @@ extern "C" int sgo_conv_tile_order(int mode) {
     return old;
 }
 
-extern "C" int sgo_conv3x3_tower_dev(int n, int h, int w, const void *d_x, const void *d_w, const void *d_bias,
-                                     const void *d_skip, void *d_y, void *stream) {
+namespace {
+// The slice loop both tower entry points share.  packed: d_w is a fragment-order filter bank (sgo_conv3x3_tower_prepack_dev) and
+// the launch goes to k_conv4r; otherwise d_w is OHWI and the launch goes to k_conv4w / k_conv8w (sgo_conv_tower_kernel).
+int tower_launch(const char *who, bool packed, int n, int h, int w, const void *d_x, const void *d_w, const void *d_bias,
+                 const void *d_skip, void *d_y, void *stream) {
     using namespace sgo;
     if (n <= 0 || h <= 0 || w <= 0 || w > sgo_conv8w::MAXW || !d_x || !d_w || !d_bias || !d_y) {
-        set_error("sgo_conv3x3_tower_dev: bad argument (256 -> 256 channels, pad 1, board width <= 19)");
+        set_error(std::string(who) + ": bad argument (256 -> 256 channels, pad 1, board width <= 19)");
         return SGO_ERR_ARG;
     }
     if ((((uintptr_t)d_x | (uintptr_t)d_w | (uintptr_t)d_y | (uintptr_t)d_skip) & 15) || ((uintptr_t)d_bias & 7)) {
-        set_error("sgo_conv3x3_tower_dev: x, w, skip, y must be 16-byte aligned (bias 8-byte): the kernel moves 16 B per lane");
+        set_error(std::string(who) + ": x, w, skip, y must be 16-byte aligned (bias 8-byte): the kernel moves 16 B per lane");
         return SGO_ERR_ARG;
     }
     // the kernel addresses pixels with 32-bit byte offsets: batches beyond 2^31 bytes per tensor run in slices
@@ -55,21 +60,54 @@ extern "C" int sgo_conv3x3_tower_dev(int n, int h, int w, const void *d_x, const
     if (max_n_div < max_n) max_n = max_n_div;
     if (g_tower_slice_cap > 0 && g_tower_slice_cap < max_n) max_n = g_tower_slice_cap;   // test hook: exercise the slice loop
     if (max_n > 256) max_n -= max_n % 256;
-    if (max_n < 1) { set_error("sgo_conv3x3_tower_dev: one sample exceeds the addressable range"); return SGO_ERR_ARG; }
+    if (max_n < 1) { set_error(std::string(who) + ": one sample exceeds the addressable range"); return SGO_ERR_ARG; }
     for (long n0 = 0; n0 < n; n0 += max_n) {
         const int nn = (int)((n - n0 < max_n) ? (n - n0) : max_n);
         const char *s0 = d_skip ? (const char *)d_skip + n0 * per : nullptr;
-        const int rc = g_tower_kernel >= 1
-                           ? sgo_conv4w::launch(nn, h, w, (const char *)d_x + n0 * per, d_w, d_bias, s0, (char *)d_y + n0 * per, (hipStream_t)stream,
-                                                g_tower_kernel >= 16 ? g_tower_kernel - 16 : 7)
-                           : sgo_conv8w::launch(nn, h, w, (const char *)d_x + n0 * per, d_w, d_bias, s0, (char *)d_y + n0 * per, (hipStream_t)stream);
+        const char *x0 = (const char *)d_x + n0 * per;
+        char *y0 = (char *)d_y + n0 * per;
+        int rc;
+        if (packed) rc = sgo_conv4r::launch(nn, h, w, x0, d_w, d_bias, s0, y0, (hipStream_t)stream, g_packed_variant);
+        else if (g_tower_kernel >= 1)
+            rc = sgo_conv4w::launch(nn, h, w, x0, d_w, d_bias, s0, y0, (hipStream_t)stream, g_tower_kernel >= 16 ? g_tower_kernel - 16 : 7);
+        else rc = sgo_conv8w::launch(nn, h, w, x0, d_w, d_bias, s0, y0, (hipStream_t)stream);
         if (rc != 0) {
-            set_error("sgo_conv3x3_tower_dev: launch rejected");
+            set_error(std::string(who) + ": launch rejected");
             return SGO_ERR_ARG;
         }
     }
     SGO_HIP(hipGetLastError());
     return SGO_OK;
+}
+}  // namespace
+
+extern "C" int sgo_conv3x3_tower_dev(int n, int h, int w, const void *d_x, const void *d_w, const void *d_bias,
+                                     const void *d_skip, void *d_y, void *stream) {
+    return tower_launch("sgo_conv3x3_tower_dev", false, n, h, w, d_x, d_w, d_bias, d_skip, d_y, stream);
+}
+
+extern "C" long sgo_conv3x3_tower_packed_bytes(void) { return sgo_conv4r::PACKED_BYTES; }
+
+extern "C" int sgo_conv3x3_tower_prepack_dev(const void *d_w, void *d_wp, void *stream) {
+    using namespace sgo;
+    if (!d_w || !d_wp || (((uintptr_t)d_w | (uintptr_t)d_wp) & 15)) {
+        set_error("sgo_conv3x3_tower_prepack_dev: w [256][3][3][256] fp16 and wp (sgo_conv3x3_tower_packed_bytes()) must be 16-byte aligned device pointers");
+        return SGO_ERR_ARG;
+    }
+    sgo_conv4r::prepack(d_w, d_wp, (hipStream_t)stream);
+    SGO_HIP(hipGetLastError());
+    return SGO_OK;
+}
+
+extern "C" int sgo_conv3x3_tower_packed_dev(int n, int h, int w, const void *d_x, const void *d_wp, const void *d_bias,
+                                            const void *d_skip, void *d_y, void *stream) {
+    return tower_launch("sgo_conv3x3_tower_packed_dev", true, n, h, w, d_x, d_wp, d_bias, d_skip, d_y, stream);
+}
+
+extern "C" int sgo_conv_packed_variant(int v) {
+    const int old = g_packed_variant;
+    if (v >= 0) g_packed_variant = v;
+    return old;
 }
 
 extern "C" int sgo_conv3x3_stem_dev(int n, int h, int w, const void *d_x, const void *d_w, const void *d_bias, void *d_y,

@@ -196,13 +196,13 @@ __global__ __launch_bounds__(256, 2) void k_conv4w(const char *__restrict__ xb, 
         }                                                                                             \
     } while (0)
 #define S4_READ_B(BUF, G, dst)                                                                        \
-    if (!(VAR & 32)) _Pragma("unroll") for (int nt_ = 0; nt_ < 2; nt_++) {                            \
+    if (!(VAR & (32 | 2048))) _Pragma("unroll") for (int nt_ = 0; nt_ < 2; nt_++) {                            \
         dst[nt_][0] = S4_LDS16(((BUF) ? LB1 : LB0) + (G) * 8192 + nt_ * 2048 + rdB0);                 \
         dst[nt_][1] = S4_LDS16(((BUF) ? LB1 : LB0) + (G) * 8192 + nt_ * 2048 + rdB1);                 \
     }
 #define S4_PRIO(x) __builtin_amdgcn_s_setprio(x)
 // ABLATION bits (timing only, wrong results; -DSGO_CONV4W_VARIANTS builds): 16 no MFMAs, 32 no fragment reads, 64 no weight
-// staging, 128 no barriers inside the K loop
+// staging, 128 no barriers inside the K loop, 2048 no WEIGHT fragment reads (the pixel reads stay)
 #define S4_MFMA(QM, QN, wfrag)                                                                         \
     if (!(VAR & 16))                                                                                   \
     _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ks_++) _Pragma("unroll") for (int mt_ = 0; mt_ < 4; mt_++) \
@@ -492,6 +492,9 @@ static inline int launch(int n, int h, int w, const void *x, const void *wgt, co
     case 263: return launch_var<263>(n, h, w, x, wgt, bias, skip, y, st);    // 7 + split wait in phase A
     case 519: return launch_var<519>(n, h, w, x, wgt, bias, skip, y, st);    // 7 + half-tile stagger of the CU's second slot
     case 1543: return launch_var<1543>(n, h, w, x, wgt, bias, skip, y, st);  // 7 + quarter-tile stagger
+    case 2055: return launch_var<2055>(n, h, w, x, wgt, bias, skip, y, st);  // ablation: no WEIGHT fragment reads (pixel reads stay)
+    case 2119: return launch_var<2119>(n, h, w, x, wgt, bias, skip, y, st);  // ... and no weight staging
+    case 2247: return launch_var<2247>(n, h, w, x, wgt, bias, skip, y, st);  // ... and no K-loop barriers: bound of a register-fed weight operand
 #endif
     default: return launch_var<7>(n, h, w, x, wgt, bias, skip, y, st);
     }

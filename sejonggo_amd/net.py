@@ -182,6 +182,10 @@ class FusedInferenceNet(object):
         self.fused_conv = True     # conv + bias + skip + ReLU in one MFMA kernel (sgo_conv.hip); False: MIOpen + k_bias_act
         self.split_min = 1024
         self._side = None
+        # tower route: False = OHWI weights through the LDS (k_conv4w, the default), True = fragment-order filter banks straight
+        # into registers (k_conv4r, csrc/sgo_conv4r.hpp; same bits, same speed on MI355X: DESIGN.md 4a) -- use_packed_tower()
+        self.packed_tower = False
+        self._banks = {}
         self.conv_events = None    # list of (start, end, flops) HIP-event brackets around tower convolutions while set (bench.py)
         self.side_flops = 0.0      # tower FLOPs issued on the side stream while conv_events is set
         self.conv_event_stride = 1  # bracket every k-th tower launch only (small batches: the event calls would bound the host)
@@ -189,6 +193,20 @@ class FusedInferenceNet(object):
 
     def flops_per_eval(self):
         return self._flops
+
+    def use_packed_tower(self, on=True):
+        """Route the tower convolutions through sgo_conv3x3_tower_packed_dev (k_conv4r).  The filter banks are written here, once
+        per layer (sgo_conv3x3_tower_prepack_dev), not on the evaluation path."""
+        if on and self.channels == 256 and self.t <= 19 and not self._banks:
+            nbytes = self.lib.sgo_conv3x3_tower_packed_bytes()
+            st = torch.cuda.current_stream().cuda_stream
+            for (w1, _, w2, _) in self.blocks:
+                for w in (w1, w2):
+                    bank = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+                    self._lib.check(self.lib.sgo_conv3x3_tower_prepack_dev(w.data_ptr(), bank.data_ptr(), st), "sgo_conv3x3_tower_prepack_dev")
+                    self._banks[w.data_ptr()] = bank
+        self.packed_tower = bool(on) and bool(self._banks)
+        return self.packed_tower
 
     def _epilogue(self, y, bias, skip=None):
         L = self._lib
@@ -224,9 +242,15 @@ class FusedInferenceNet(object):
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        self._lib.check(self.lib.sgo_conv3x3_bias_act_dev(n, h, wd, c, k, pad, x.data_ptr(), w.data_ptr(), b.data_ptr(),
-                                                          None if skip is None else skip.data_ptr(), y.data_ptr(),
-                                                          torch.cuda.current_stream().cuda_stream), "sgo_conv3x3_bias_act_dev")
+        bank = self._banks.get(w.data_ptr()) if self.packed_tower and c == k == 256 and pad == 1 else None
+        if bank is not None:
+            self._lib.check(self.lib.sgo_conv3x3_tower_packed_dev(n, h, wd, x.data_ptr(), bank.data_ptr(), b.data_ptr(),
+                                                              None if skip is None else skip.data_ptr(), y.data_ptr(),
+                                                              torch.cuda.current_stream().cuda_stream), "sgo_conv3x3_tower_packed_dev")
+        else:
+            self._lib.check(self.lib.sgo_conv3x3_bias_act_dev(n, h, wd, c, k, pad, x.data_ptr(), w.data_ptr(), b.data_ptr(),
+                                                              None if skip is None else skip.data_ptr(), y.data_ptr(),
+                                                              torch.cuda.current_stream().cuda_stream), "sgo_conv3x3_bias_act_dev")
         if timed:
             e1.record()
             self.conv_events.append((e0, e1, 2.0 * n * y.shape[2] * y.shape[3] * 9 * c * k))

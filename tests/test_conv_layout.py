@@ -107,3 +107,28 @@ def test_epilogue_image_round_trip_and_b64_conflicts():
         a = wid * 8192 + j * 1024 + lane * 16
         row = wid * 16 + j * 2 + (lane >> 5)
         assert image[(a // 512, (a % 512) // 16)] == (row, (lane & 31) ^ (j * 2 + (lane >> 5)))
+
+
+def test_packed_filter_bank_feeds_the_same_fragments_as_the_lds_route():
+    """k_conv4r (csrc/sgo_conv4r.hpp) loads its weight fragments from a bank in fragment order (k_prepack).  Restated here:
+    piece i of the bank (16 bytes) -> (filter, tap, first input channel).  Claims: (1) the pieces of the four wave banks are a
+    permutation of the filter bank's 16-byte pieces (nothing lost, nothing twice); (2) lane l of fragment (lo / hi, nt, ks) of
+    K-tile t holds what the same lane reads from k_conv4w's LDS image -- filter = half * 128 + qn * 64 + wc * 32 + nt * 16 +
+    (l & 15), input channels cc * 64 + ks * 32 + (l >> 4) * 8 .. + 8 of tap T -- so both kernels issue identical MFMAs;
+    (3) a wave's load group (4 fragments) is 4 KB contiguous and its K-tiles follow each other in loop order."""
+    WAVE_BANK = 36 * 8192
+    seen = set()
+    for i in range(4 * WAVE_BANK // 16):
+        lane, ks, nt, qn = i & 63, (i >> 6) & 1, (i >> 7) & 1, (i >> 8) & 1
+        t, g = (i >> 9) % 36, (i >> 9) // 36
+        cc, T = t // 9, t % 9
+        half, wc = g >> 1, g & 1
+        filt = half * 128 + qn * 64 + wc * 32 + nt * 16 + (lane & 15)
+        ci = cc * 64 + ks * 32 + (lane >> 4) * 8
+        # (2): k_conv4w's image row / chunk for this lane (test above): granule G = qn, row wc*32 + nt*16 + (l & 15), chunk (l >> 4) + 4 ks
+        assert filt == half * 128 + qn * 64 + (wc * 32 + nt * 16 + (lane & 15)) and ci == cc * 64 + ((lane >> 4) + 4 * ks) * 8
+        assert 0 <= filt < 256 and 0 <= ci <= 248 and ci % 8 == 0
+        seen.add((filt, T, ci))
+        # (3): byte address inside the wave bank = K-tile * 8192 + group * 4096 + fragment * 1024 + lane * 16
+        assert i * 16 == g * WAVE_BANK + t * 8192 + qn * 4096 + (nt * 2 + ks) * 1024 + lane * 16
+    assert len(seen) == 256 * 9 * 32                     # (1)

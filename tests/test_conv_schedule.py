@@ -280,3 +280,139 @@ def test_conv4w_model_rejects_a_too_early_restage():
         run_wave4(wid, 17, True, early=5)
     with pytest.raises(AssertionError):
         run_wave4(3, 7, True, early=5)           # wave 3's fifth piece covers rows 152..159; phase B reads from row 144 on
+
+
+# ---- k_conv4r (csrc/sgo_conv4r.hpp): the weights go L2 -> registers; three rotating register sets; both tile forms -------------
+HDR4R = os.path.join(os.path.dirname(HDR), "sgo_conv4r.hpp")
+
+
+def test_conv4r_model_is_in_step_with_the_kernel_source():
+    s = open(HDR4R).read()
+    assert "constexpr int SLO_ = (2 * (T)) % 3, SHI_ = (2 * (T) + 1) % 3, SNX_ = (2 * (T) + 2) % 3;" in s
+    assert s.count("const bool boundary_ = (T) == 8 && cc < 3;") == 2 and s.count("const bool restaged_ = (T) == 0 && cc > 0;") == 2
+    # grouped form (R4_TILE): L(2t+2) at the start of phase A, L(2t+3) between the two MFMA groups of phase B
+    assert re.search(r"R4_LOADW\(SNX_\);[^\n]*\n\s*R4_READ_A\(0, T\);", s)
+    assert "if (restaged_) R4_VMWAIT_LATE(8);" in s and "else R4_VMWAITW(8);" in s
+    assert "if (boundary_) R4_VMWAIT(8);" in s and "else R4_VMWAITW(4);" in s
+    assert "if (!(VAR & 2)) R4_LOADW(SLO_);" in s and "R4_VMWAIT_LATE(4);" in s
+    # spread form (R4_TILE_S): two pieces of L(2t+2) in each half of phase A's burst, L(2t+3) in the second half of phase B's
+    assert "if (restaged_) R4_VMWAIT_LATE(4);" in s and "if (boundary_) R4_VMWAIT(6);" in s and "else R4_VMWAITW(2);" in s
+    assert "R4_G2(0, 0, SLO_, SNX_, 0);" in s and "R4_G2(0, 1, SHI_, SNX_, 2);" in s and "R4_G4(1, 1, SHI_, SLO_);" in s
+    assert "R4_VMWAIT_LATE(8);" in s
+    assert "if (nlate == 6) { R4_VMWAIT_SUM(base, 6); }" in s and "else { R4_VMWAIT_SUM(base, 0); }" in s
+    assert "for (int pc = 4; pc < 10; pc++) nlate += ((pc * 4 + wid) * 8 < NROWS) ? 1 : 0;" in s
+    assert re.search(r"R4_STAGE_WP\(0, 0, 10\);\s*R4_LOADW\(0\);\s*R4_LOADW\(1\);", s)
+    assert "R4_VMWAIT(8);                                        // the window has landed; in flight: L(0), L(1)" in s
+    assert "R4_STAGE_WP((cc + 1) * 128, 0, 4);" in s and "R4_STAGE_WP((cc + 1) * 128, 4, 10);" in s
+    assert "default: return launch_var<1>(n, h, w, x, wpk, bias, skip, y, st);" in s       # grouped form + priorities is what ships
+
+
+def run_wave4r(wid, W, has_skip, spread, drop_drain=False):
+    """Issue order and counted waits of one wave of k_conv4r.  Besides 'what is read next has landed' this checks the REGISTER
+    claim of the three-set rotation: a load group is issued into a set only after the last MFMA group that reads the set's
+    previous contents."""
+    nrows = 256 + 2 * (W + 1)
+    w = Wave()
+    nlate = sum(1 for pc in range(4, 10) if (pc * 4 + wid) * 8 < nrows)
+    late_wait = lambda base: base + (nlate if nlate in (4, 5, 6) else 0)
+    holds = {}                                   # set -> load group it holds (or is about to receive)
+    busy = {}                                    # set -> True while MFMA groups of the current K-tile still read it
+
+    def pieces(chunk, pc0, pc1):
+        out = []
+        for pc in range(pc0, pc1):
+            idn = pc * 4 + wid
+            if idn * 8 < nrows:
+                w.issue(("win", chunk, idn))
+                out.append(("win", chunk, idn))
+        return out
+
+    def load(j, s, ps=range(4)):
+        assert not busy.get(s), "load group %d into set %d while MFMAs still read it" % (j, s)
+        holds[s] = j
+        for p in ps:
+            w.issue(("L", j, p))
+
+    def need(j, s, n, where):
+        assert holds.get(s) == j, "%s: set %d holds group %r, not %d" % (where, s, holds.get(s), j)
+        w.wait(n, [("L", j, p) for p in range(4)], where)
+
+    win0 = pieces(0, 0, 10)
+    load(0, 0)
+    load(1, 1)
+    w.wait(8, win0, "prologue")
+    for cc in range(4):
+        for T in range(9):
+            t = 9 * cc + T
+            slo, shi, snx = (2 * T) % 3, (2 * T + 1) % 3, (2 * T + 2) % 3
+            where = "K-tile %d (wave %d, w %d, %s)" % (t, wid, W, "spread" if spread else "grouped")
+            boundary, restaged = T == 8 and cc < 3, T == 0 and cc > 0
+            busy[slo] = busy[shi] = True
+            # ---- phase A
+            if not spread:
+                load(2 * t + 2, snx)
+            need(2 * t, slo, (late_wait(8) if restaged else 8) if not spread else (late_wait(4) if restaged else 4), where + " lo")
+            if boundary:
+                early = pieces(cc + 1, 0, 4)
+                assert len(early) == 4
+                assert all((tag[2] + 1) * 8 <= 128 + 2 * (W + 1) for tag in early), where      # rows phase B no longer reads
+            if spread:
+                load(2 * t + 2, snx, (0, 1))
+                need(2 * t + 1, shi, 6 if boundary else 2, where + " hi")
+                for p in (2, 3):
+                    w.issue(("L", 2 * t + 2, p))
+            else:
+                need(2 * t + 1, shi, 8 if boundary else 4, where + " hi")
+            if restaged:                         # barrier: every wave's late pieces must have been retired by the wait above
+                late = [("win", cc, pc * 4 + wid) for pc in range(4, 10) if (pc * 4 + wid) * 8 < nrows]
+                w.wait(2 if spread else 4, late, where + " late pieces")
+            # ---- phase B
+            if boundary:
+                pieces(cc + 1, 4, 10)
+            busy[slo] = False                    # MFMA(1, lo) is the set's last reader
+            load(2 * t + 3, slo)
+            busy[shi] = False
+            if boundary:
+                w.wait(late_wait(8 if spread else 4), early, where + " boundary (early pieces)")
+    if not drop_drain:
+        w.wait(0, [("L", 72, p) for p in range(4)] + [("L", 73, p) for p in range(4)], "drain of the look-ahead loads")
+    for q in range(4):
+        w.issue(("bias", q))
+    if has_skip:
+        for hf in (0, 1):
+            for j in range(8):
+                w.issue(("skip", hf, j))
+    for hf in (0, 1):
+        if has_skip:
+            w.wait(8, [("skip", hf, j) for j in range(8)] + [("bias", q) for q in range(4)], "epilogue half %d" % hf)
+        elif hf == 0:
+            w.wait(0, [("bias", q) for q in range(4)], "epilogue (no skip)")
+        for j in range(8):
+            w.issue(("store", hf, j))
+    return w
+
+
+def test_conv4r_counted_waits_and_register_sets():
+    for spread in (False, True):
+        for W in (1, 3, 5, 7, 9, 13, 17, 19):
+            for has_skip in (False, True):
+                for wid in range(4):
+                    run_wave4r(wid, W, has_skip, spread)
+
+
+def test_conv4r_model_rejects_a_weaker_wait():
+    """The model must notice a wait that leaves a needed group in flight: replay with every 'hi' wait one group too weak."""
+    import pytest
+    real = Wave.wait
+
+    def weak(self, n, need, where):
+        return real(self, n + 4 if where.endswith(" hi") else n, need, where)
+
+    Wave.wait = weak
+    try:
+        with pytest.raises(AssertionError):
+            run_wave4r(0, 17, True, False)
+        with pytest.raises(AssertionError):
+            run_wave4r(0, 17, True, True)
+    finally:
+        Wave.wait = real

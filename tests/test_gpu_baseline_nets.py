@@ -129,6 +129,12 @@ def test_tower_conv_at_the_headline_launch(L):
     y2 = torch.empty_like(y)
     L.check(lib.sgo_conv3x3_tower_dev(n, h, wd, x.data_ptr(), w.data_ptr(), b.data_ptr(), skip.data_ptr(), y2.data_ptr(), st))
     assert torch.equal(y, y2)
+    # the register-fed kernel (k_conv4r, filter bank in fragment order) at the same launch: identical bits
+    bank = torch.empty(lib.sgo_conv3x3_tower_packed_bytes(), device="cuda", dtype=torch.uint8)
+    L.check(lib.sgo_conv3x3_tower_prepack_dev(w.data_ptr(), bank.data_ptr(), st))
+    y2.fill_(7.0)
+    L.check(lib.sgo_conv3x3_tower_packed_dev(n, h, wd, x.data_ptr(), bank.data_ptr(), b.data_ptr(), skip.data_ptr(), y2.data_ptr(), st))
+    assert torch.equal(y, y2)
 
 
 def test_config2_batch_shape_equals_the_oracle_on_sampled_slots(L):

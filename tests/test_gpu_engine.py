@@ -1209,6 +1209,114 @@ def test_tower_kernels_agree_bit_for_bit(L):
         assert torch.equal(outs[0], outs[1]), (n, h, wd, with_skip)       # same MFMA order per output: identical bits
 
 
+def test_packed_tower_kernel(L):
+    """sgo_conv3x3_tower_packed_dev (k_conv4r, csrc/sgo_conv4r.hpp: weights from a fragment-order filter bank straight into
+    registers): against torch conv2d in fp32 (fp16 output rounding: 2e-3 relative + 2e-3 absolute), bit for bit against
+    sgo_conv3x3_tower_dev (same MFMA order per output), bit-identical across relaunches (the race screen of its counted waits),
+    exact on integer data, through the slice loop, on full / ragged / single-tile / degenerate boards; bad arguments are errors."""
+    import torch
+    import torch.nn.functional as F
+    lib = L.load()
+    torch.manual_seed(21)
+    st = torch.cuda.current_stream().cuda_stream
+    nbytes = lib.sgo_conv3x3_tower_packed_bytes()
+    assert nbytes == 4 * 36 * 8192 + 8192
+
+    def bank_of(w):
+        bank = torch.full((nbytes,), 0x5A, device="cuda", dtype=torch.uint8)
+        L.check(lib.sgo_conv3x3_tower_prepack_dev(w.data_ptr(), bank.data_ptr(), st))
+        return bank
+
+    for (n, h, wd, with_skip) in [(1, 7, 7, True), (1, 17, 17, False), (3, 17, 17, True), (5, 17, 17, False), (64, 7, 7, True),
+                                  (7, 5, 19, True), (2, 19, 19, False), (333, 17, 17, True), (1024, 17, 17, True),
+                                  (300, 11, 1, False), (9, 1, 1, True), (40, 1, 13, True), (77, 2, 2, False), (700, 9, 9, True)]:
+        x = (torch.randn(n, h, wd, 256, device="cuda") * 0.5).half()
+        w = (torch.randn(256, 3, 3, 256, device="cuda") * 0.03).half()
+        b = torch.randn(256, device="cuda").half()
+        skip = torch.randn(n, h, wd, 256, device="cuda").half() if with_skip else None
+        sp = None if skip is None else skip.data_ptr()
+        bank = bank_of(w)
+        # the bank is a permutation of the filter bank's bytes (+ 8 KB of zero padding the last K-tile's look-ahead reads)
+        assert torch.equal(torch.sort(bank[:nbytes - 8192].view(torch.int16)).values, torch.sort(w.view(torch.int16).reshape(-1)).values)
+        assert int(bank[nbytes - 8192:].sum()) == 0
+        y = torch.full((n, h, wd, 256), 7.0, device="cuda", dtype=torch.float16)
+        L.check(lib.sgo_conv3x3_tower_packed_dev(n, h, wd, x.data_ptr(), bank.data_ptr(), b.data_ptr(), sp, y.data_ptr(), st))
+        ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), b.float(), padding=1).permute(0, 2, 3, 1)
+        if with_skip:
+            ref = ref + skip.float()
+        ref = torch.relu(ref)
+        err = (y.float() - ref).abs()
+        assert bool((err <= 2e-3 * ref.abs() + 2e-3).all()), (n, h, wd, with_skip, float(err.max()))
+        y1 = torch.full_like(y, 5.0)
+        L.check(lib.sgo_conv3x3_tower_dev(n, h, wd, x.data_ptr(), w.data_ptr(), b.data_ptr(), sp, y1.data_ptr(), st))
+        assert torch.equal(y, y1), (n, h, wd, with_skip)
+        for _ in range(3):
+            y3 = torch.full_like(y, 3.0)
+            L.check(lib.sgo_conv3x3_tower_packed_dev(n, h, wd, x.data_ptr(), bank.data_ptr(), b.data_ptr(), sp, y3.data_ptr(), st))
+            assert torch.equal(y, y3)
+    # the slice loop (sample cap hook) on ragged slice sizes
+    x = (torch.randn(700, 17, 17, 256, device="cuda") * 0.5).half()
+    skip = torch.randn_like(x)
+    whole = torch.empty_like(x)
+    L.check(lib.sgo_conv3x3_tower_packed_dev(700, 17, 17, x.data_ptr(), bank.data_ptr(), b.data_ptr(), skip.data_ptr(), whole.data_ptr(), st))
+    for cap in (1, 255, 300):
+        assert lib.sgo_conv_tower_slice_cap(cap) == 0
+        try:
+            part = torch.empty_like(x)
+            L.check(lib.sgo_conv3x3_tower_packed_dev(700, 17, 17, x.data_ptr(), bank.data_ptr(), b.data_ptr(), skip.data_ptr(), part.data_ptr(), st))
+            assert torch.equal(part, whole), cap
+        finally:
+            lib.sgo_conv_tower_slice_cap(0)
+    del x, skip, whole, part
+    # race screen at a chip-filling size: a missing wait shows up as run-to-run differences
+    n, h, wd = 4096, 17, 17
+    x = (torch.randn(n, h, wd, 256, device="cuda") * 0.5).half()
+    skip = torch.randn(n, h, wd, 256, device="cuda").half()
+    y = torch.empty_like(skip)
+    L.check(lib.sgo_conv3x3_tower_packed_dev(n, h, wd, x.data_ptr(), bank.data_ptr(), b.data_ptr(), skip.data_ptr(), y.data_ptr(), st))
+    y0 = y.clone()
+    for _ in range(25):
+        y.fill_(1.0)
+        L.check(lib.sgo_conv3x3_tower_packed_dev(n, h, wd, x.data_ptr(), bank.data_ptr(), b.data_ptr(), skip.data_ptr(), y.data_ptr(), st))
+        assert torch.equal(y, y0)
+    del x, skip, y, y0
+    # exact integer data
+    n, h, wd = 4, 17, 17
+    x = torch.randint(-2, 3, (n, h, wd, 256), device="cuda").half()
+    w = torch.randint(-1, 2, (256, 3, 3, 256), device="cuda").half()
+    b = torch.randint(-3, 4, (256,), device="cuda").half()
+    y = torch.empty(n, h, wd, 256, device="cuda", dtype=torch.float16)
+    bank = bank_of(w)
+    L.check(lib.sgo_conv3x3_tower_packed_dev(n, h, wd, x.data_ptr(), bank.data_ptr(), b.data_ptr(), None, y.data_ptr(), st))
+    ref = torch.relu(F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), b.float(), padding=1)).permute(0, 2, 3, 1)
+    assert float(ref.max()) < 2048 and torch.equal(y.float(), ref)
+    # errors, not fall-backs
+    assert lib.sgo_conv3x3_tower_packed_dev(1, 21, 21, x.data_ptr(), bank.data_ptr(), b.data_ptr(), None, y.data_ptr(), st) < 0
+    assert lib.sgo_conv3x3_tower_packed_dev(n, h, wd, x.data_ptr(), None, b.data_ptr(), None, y.data_ptr(), st) < 0
+    assert lib.sgo_conv3x3_tower_prepack_dev(w.data_ptr() + 2, bank.data_ptr(), st) < 0
+    assert lib.sgo_conv3x3_tower_prepack_dev(None, bank.data_ptr(), st) < 0
+
+
+def test_packed_tower_route_of_the_net_equals_the_default_route(L):
+    """net.FusedInferenceNet.use_packed_tower(): the whole 4-block 9x9 net (BASELINE config 2's) with its tower on k_conv4r gives
+    the policy / value bits of the default route (k_conv4w)."""
+    import torch
+    from sejonggo_amd.net import build_fused_net
+    L.load()
+    net, _ = build_fused_net(9, 4, 256, name="packed_route", seed=5, device="cuda")
+    X = torch.zeros(96, 9, 9, 17, device="cuda", dtype=torch.float16)
+    g = torch.Generator(device="cuda").manual_seed(2)
+    X[..., :16] = (torch.rand(96, 9, 9, 16, device="cuda", generator=g) < 0.2).half()
+    X[..., 16] = 1.0
+    p0, v0 = net.predict_on_batch(X)
+    assert net.use_packed_tower(True) and len(net._banks) == 8
+    p1, v1 = net.predict_on_batch(X)
+    assert torch.equal(p0, p1) and torch.equal(v0, v1)
+    assert not net.use_packed_tower(False)
+    p2, v2 = net.predict_on_batch(X)
+    assert torch.equal(p0, p2) and torch.equal(v0, v2)
+
+
 def test_tower_conv_tile_order_slices_and_bounds(L, tower_kernel):
     """The tower kernel's launch plumbing: (1) both tile orders (identity, XCD-contiguous incl. grids that are not a
     multiple of 8) give identical bits; (2) the slice loop of sgo_conv3x3_tower_dev, normally reached only beyond 2^31 bytes
