@@ -74,6 +74,9 @@ constexpr int LB0 = 0, LB1 = 16384, LW = 32768, LZ = 73728, LZ_BYTES = 3 * 2048 
 //   A leaner instruction stream (v_bfe / v_bfi mask select, phase B reusing phase A's row address, scalar weight-staging
 //   addresses: 37 instead of 60 VALU per K-tile) ran 3.5 % SLOWER: differences of this size are inside the band that code
 //   placement alone moves a hipcc-built kernel by (guide rule 27), so nothing below ~3 % is claimed as a schedule effect.
+//   Priorities by hardware wave slot (round 3; the two waves of a SIMD belong to two workgroups and sit in slots 0 / 1, HW_ID bit 0):
+//   one static priority per wave for the whole kernel, no flips (-3.3 %), or flips to 2 instead of 1 in odd slots so that two
+//   colliding bursts are not a tie (-4.9 %); gpurun_out/r03ax_prio.log.
 //   What DOES matter is the ORDER of the fragment reads: the two K-halves of a row (addresses a, a ^ 64: complementary LDS
 //   banks) back to back, as S4_READ_A issues them, is 5 % faster than all K-half-0 reads followed by all K-half-1 reads.
 template <bool HAS_SKIP, int VAR>
