@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--sims", type=int, default=80)
     ap.add_argument("--moves", type=int, default=40)
     ap.add_argument("--blocks", type=int, default=6)
+    ap.add_argument("--packed-tower", type=int, default=0, help="1: a third run with the tower on k_conv4r (net.use_packed_tower): same games bit for bit")
     a = ap.parse_args()
     import numpy as np
     import random
@@ -24,7 +25,9 @@ def main():
     from sejonggo_amd.net import build_fused_net
     net, _ = build_fused_net(a.size, a.blocks, 256, name="det", seed=3, device="cuda")
     digests = []
-    for rep in range(2):
+    for rep in range(3 if a.packed_tower else 2):
+        if rep == 2:
+            assert net.use_packed_tower(True)
         random.seed(11)                      # the per-batch symmetry choice
         eng = SelfPlayEngine(net, size=a.size, n_games=a.games, sims=a.sims, energy=8, stop_exploration=30, num_moves=a.moves,
                              symmetry="random1", seed=5)
@@ -42,6 +45,9 @@ def main():
         print("run %d: %d games, %d moves, digest %s" % (rep, len(games), n_moves, digests[-1]), flush=True)
         eng.close()
     assert digests[0] == digests[1], "self-play is not reproducible"
+    if a.packed_tower:
+        assert digests[2] == digests[0], "the packed tower route (k_conv4r) plays different games"
+        print("packed tower route: identical games")
     print("deterministic")
 
 
