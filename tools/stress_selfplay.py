@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--json", default="", help="write the summary as JSON to this path")
     ap.add_argument("--energy", type=int, default=8)
     ap.add_argument("--no-resign", type=int, default=0, help="1: RESIGNATION_PERCENT = 1 (every game runs to its natural end)")
+    ap.add_argument("--packed-tower", type=int, default=0, help="1: the tower on k_conv4r (net.use_packed_tower)")
     a = ap.parse_args()
     import numpy as np
     from sejonggo_amd import predicting_queue_worker as pq
@@ -55,6 +56,8 @@ def main():
         fnet.name = "stress"
     else:
         fnet, _ = build_fused_net(a.size, a.blocks, a.channels, name="stress")
+    if a.packed_tower:
+        assert fnet.use_packed_tower(True), "the packed tower route needs the reference's 256-channel shape"
     pq.set_model_factory(lambda kind: fnet)
     lens, results = [], []
     probe = {}
