@@ -416,3 +416,28 @@ def test_conv4r_model_rejects_a_weaker_wait():
             run_wave4r(0, 17, True, True)
     finally:
         Wave.wait = real
+
+
+def test_conv4r_isa_leaves_load_destinations_alone_until_their_wait():
+    """The compiled k_conv4r (both instantiations that ship): between a register load's issue and the counted wait that retires it,
+    no instruction reads or writes its destination (tools/vmcnt_isa_check.py; the hazard behind it is in that file's header).
+    Control: with the waits deleted from the same text the checker must report violations."""
+    import importlib.util
+    import pytest
+    spec = importlib.util.spec_from_file_location("vmcnt_isa_check", os.path.join(os.path.dirname(os.path.dirname(HDR)), "..", "tools", "vmcnt_isa_check.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    asm = chk.device_asm()
+    if asm is None:
+        pytest.skip("no hipcc")
+    for skip in (1, 0):
+        k = chk.kernel_text(asm, "_ZN10sgo_conv4r8k_conv4rILb%dELi1E" % skip)
+        assert k is not None
+        first, last = chk.k_loop(k)
+        assert sum("v_mfma" in l for l in k[first:last + 1]) == 9 * 64          # the whole K loop body: 9 taps x 64 MFMAs
+        bad, loads = chk.check(k, first, last)
+        assert loads == 9 * 8 and not bad, bad[:5]
+        no_waits = [l for l in k if "vmcnt" not in l]
+        f2, l2 = chk.k_loop(no_waits)
+        bad2, _ = chk.check(no_waits, f2, l2)
+        assert bad2, "the checker did not notice loads that are never waited for"
