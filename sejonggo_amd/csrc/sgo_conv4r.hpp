@@ -55,7 +55,7 @@ constexpr int LW = 0, LZ = 40960, LZ_BYTES = 3 * 2048 + 256, LDS_BYTES = 65536;
     __builtin_amdgcn_sched_barrier(0)
 
 // VAR bit 0: s_setprio(1) around the MFMA bursts; bit 1: the look-ahead load of hi(t+1) is issued at the END of phase B instead
-// of between its two MFMA groups.  ABLATION bit (timing only, wrong results; -DSGO_CONV4W_VARIANTS builds): 4 no weight loads.
+// of between its two MFMA groups.  ABLATION bits (timing only, wrong results; -DSGO_CONV4W_VARIANTS builds): 4 no weight loads, 32 no window DMA in the prologue.
 // (There is no "loads without waits" ablation: a load that lands after the compiler has given its registers to something else --
 // an address, say -- corrupts it; the one run of such a variant ended in a memory access fault.)
 template <bool HAS_SKIP, int VAR>
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256, 2) void k_conv4r(const char *__restrict__ xb, 
     // ---- prologue: window of chunk 0, weights of K-tile 0
     {
         int swid = wid;
-        R4_STAGE_WP(0, 0, 10);
+        if (!(VAR & 32)) R4_STAGE_WP(0, 0, 10);           // ablation bit 32: no window DMA in the prologue (a prologue hidden elsewhere)
         R4_LOADW(0);
         R4_LOADW(1);
     }
@@ -511,6 +511,7 @@ static inline int launch(int n, int h, int w, const void *x, const void *wpk, co
     case 3: return launch_var<3>(n, h, w, x, wpk, bias, skip, y, st);
     case 5: return launch_var<5>(n, h, w, x, wpk, bias, skip, y, st);        // ablations
     case 17: return launch_var<17>(n, h, w, x, wpk, bias, skip, y, st);      // loads spread inside the bursts
+    case 33: return launch_var<33>(n, h, w, x, wpk, bias, skip, y, st);      // ablation: chunk 0's window is not staged
     case 21: return launch_var<21>(n, h, w, x, wpk, bias, skip, y, st);
 #endif
     default: return launch_var<1>(n, h, w, x, wpk, bias, skip, y, st);
