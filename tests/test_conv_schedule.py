@@ -301,7 +301,7 @@ def test_conv4r_model_is_in_step_with_the_kernel_source():
     assert "R4_VMWAIT_LATE(8);" in s
     assert "if (nlate == 6) { R4_VMWAIT_SUM(base, 6); }" in s and "else { R4_VMWAIT_SUM(base, 0); }" in s
     assert "for (int pc = 4; pc < 10; pc++) nlate += ((pc * 4 + wid) * 8 < NROWS) ? 1 : 0;" in s
-    assert re.search(r"R4_STAGE_WP\(0, 0, 10\);\s*R4_LOADW\(0\);\s*R4_LOADW\(1\);", s)
+    assert re.search(r"if \(!\(VAR & 32\)\) R4_STAGE_WP\(0, 0, 10\);[^\n]*\n\s*R4_LOADW\(0\);\s*R4_LOADW\(1\);", s)
     assert "R4_VMWAIT(8);                                        // the window has landed; in flight: L(0), L(1)" in s
     assert "R4_STAGE_WP((cc + 1) * 128, 0, 4);" in s and "R4_STAGE_WP((cc + 1) * 128, 4, 10);" in s
     assert "default: return launch_var<1>(n, h, w, x, wpk, bias, skip, y, st);" in s       # grouped form + priorities is what ships
