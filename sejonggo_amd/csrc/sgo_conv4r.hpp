@@ -55,7 +55,7 @@ constexpr int LW = 0, LZ = 40960, LZ_BYTES = 3 * 2048 + 256, LDS_BYTES = 65536;
     __builtin_amdgcn_sched_barrier(0)
 
 // VAR bit 0: s_setprio(1) around the MFMA bursts; bit 1: the look-ahead load of hi(t+1) is issued at the END of phase B instead
-// of between its two MFMA groups.  ABLATION bits (timing only, wrong results; -DSGO_CONV4W_VARIANTS builds): 4 no weight loads, 32 no window DMA in the prologue.
+// of between its two MFMA groups.  ABLATION bits (timing only, wrong results; -DSGO_CONV4W_VARIANTS builds): 4 no weight loads, 32 no window DMA in the prologue, 64 no pixel fragment reads.
 // (There is no "loads without waits" ablation: a load that lands after the compiler has given its registers to something else --
 // an address, say -- corrupts it; the one run of such a variant ended in a memory access fault.)
 template <bool HAS_SKIP, int VAR>
@@ -98,6 +98,10 @@ __global__ __launch_bounds__(256, 2) void k_conv4r(const char *__restrict__ xb, 
 #pragma unroll
                 for (int d = 0; d < 2; d++) acc[a][b][c][d] = floatx4{0.f, 0.f, 0.f, 0.f};
     half8 pa[4][2];
+    if (VAR & 64) {                                      // ablation: the pixel fragments are never read
+#pragma unroll
+        for (int i_ = 0; i_ < 8; i_++) asm volatile("" : "=v"(pa[i_ >> 1][i_ & 1]));
+    }
     half8 ws[3][2][2];                                   // [set][nt][ks]
     if (VAR & 4) {
 #pragma unroll
@@ -141,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void k_conv4r(const char *__restrict__ xb, 
 #define R4_LDS16(off) (*reinterpret_cast<const half8 *>(smem + (off)))
 #define R4_SHIFT(T) (((T) / 3 == 0 ? -W : (T) / 3 == 2 ? W : 0) + (T) % 3 - 1)
 #define R4_READ_A(G, T)                                                                               \
-    do {                                                                                              \
+    if (!(VAR & 64)) do {                                                                             \
         int ra_ = rowA;                                                                               \
         asm volatile("" : "+v"(ra_));                                                                 \
         const int rl_ = ra_ + R4_SHIFT(T);                                                            \
@@ -511,6 +515,8 @@ static inline int launch(int n, int h, int w, const void *x, const void *wpk, co
     case 3: return launch_var<3>(n, h, w, x, wpk, bias, skip, y, st);
     case 5: return launch_var<5>(n, h, w, x, wpk, bias, skip, y, st);        // ablations
     case 17: return launch_var<17>(n, h, w, x, wpk, bias, skip, y, st);      // loads spread inside the bursts
+    case 65: return launch_var<65>(n, h, w, x, wpk, bias, skip, y, st);      // ablation: no pixel fragment reads (weight loads stay)
+    case 69: return launch_var<69>(n, h, w, x, wpk, bias, skip, y, st);      // ablation: neither
     case 33: return launch_var<33>(n, h, w, x, wpk, bias, skip, y, st);      // ablation: chunk 0's window is not staged
     case 21: return launch_var<21>(n, h, w, x, wpk, bias, skip, y, st);
 #endif
