@@ -55,7 +55,12 @@ constexpr int LW = 0, LZ = 40960, LZ_BYTES = 3 * 2048 + 256, LDS_BYTES = 65536;
     __builtin_amdgcn_sched_barrier(0)
 
 // VAR bit 0: s_setprio(1) around the MFMA bursts; bit 1: the look-ahead load of hi(t+1) is issued at the END of phase B instead
-// of between its two MFMA groups.  ABLATION bits (timing only, wrong results; -DSGO_CONV4W_VARIANTS builds): 4 no weight loads, 32 no window DMA in the prologue, 64 no pixel fragment reads.
+// of between its two MFMA groups.  ABLATION bits (timing only, wrong results; -DSGO_CONV4W_VARIANTS builds): 4 no weight loads, 32 no window DMA in the prologue, 64 no pixel fragment reads, 128 no restage (and no barrier) at the chunk boundaries.
+// Measured and dropped (round 3): a DOUBLE-BUFFERED window for board widths <= 17 (two 292-row buffers + the zero area = 81 152 B,
+// two workgroups per CU still fit; the next chunk's pieces staged two per tap at the start of taps 0..4 with the lanes beyond the
+// window masked off, ONE barrier per chunk boundary, no drain): bit-identical, 252 VGPRs, and 3.2 % SLOWER (2.180 vs 2.112 ms in
+// one process, gpurun_out/r03bi_ab.log) although the boundaries' restage + barriers are worth 5.9 % when ablated away together
+// (variant 129): what costs at the boundaries is the window DMA itself, not the synchronisation around it.
 // (There is no "loads without waits" ablation: a load that lands after the compiler has given its registers to something else --
 // an address, say -- corrupts it; the one run of such a variant ended in a memory access fault.)
 template <bool HAS_SKIP, int VAR>
@@ -181,8 +186,8 @@ __global__ __launch_bounds__(256, 2) void k_conv4r(const char *__restrict__ xb, 
         constexpr int SLO_ = (2 * (T)) % 3, SHI_ = (2 * (T) + 1) % 3, SNX_ = (2 * (T) + 2) % 3;           \
         int swid = wid;                                                                                   \
         asm volatile("" : "+s"(swid));                                                                    \
-        const bool boundary_ = (T) == 8 && cc < 3;  /* last tap of a chunk that has a successor */        \
-        const bool restaged_ = (T) == 0 && cc > 0;  /* first tap on a restaged window */                  \
+        const bool boundary_ = !(VAR & 128) && (T) == 8 && cc < 3;  /* last tap of a chunk that has a successor (ablation bit 128: the window is never restaged) */        \
+        const bool restaged_ = !(VAR & 128) && (T) == 0 && cc > 0;  /* first tap on a restaged window */                  \
         /* ---- phase A */                                                                                \
         R4_LOADW(SNX_);                           /* L(2t+2) = lo(t+1) */                                  \
         R4_READ_A(0, T);                                                                                  \
@@ -517,6 +522,8 @@ static inline int launch(int n, int h, int w, const void *x, const void *wpk, co
     case 17: return launch_var<17>(n, h, w, x, wpk, bias, skip, y, st);      // loads spread inside the bursts
     case 65: return launch_var<65>(n, h, w, x, wpk, bias, skip, y, st);      // ablation: no pixel fragment reads (weight loads stay)
     case 69: return launch_var<69>(n, h, w, x, wpk, bias, skip, y, st);      // ablation: neither
+    case 129: return launch_var<129>(n, h, w, x, wpk, bias, skip, y, st);    // ablation: no window restage / no barriers at the chunk boundaries
+    case 197: return launch_var<197>(n, h, w, x, wpk, bias, skip, y, st);    // ... on top of 69 (no operand traffic at all)
     case 33: return launch_var<33>(n, h, w, x, wpk, bias, skip, y, st);      // ablation: chunk 0's window is not staged
     case 21: return launch_var<21>(n, h, w, x, wpk, bias, skip, y, st);
 #endif

@@ -289,7 +289,7 @@ HDR4R = os.path.join(os.path.dirname(HDR), "sgo_conv4r.hpp")
 def test_conv4r_model_is_in_step_with_the_kernel_source():
     s = open(HDR4R).read()
     assert "constexpr int SLO_ = (2 * (T)) % 3, SHI_ = (2 * (T) + 1) % 3, SNX_ = (2 * (T) + 2) % 3;" in s
-    assert s.count("const bool boundary_ = (T) == 8 && cc < 3;") == 2 and s.count("const bool restaged_ = (T) == 0 && cc > 0;") == 2
+    assert s.count("(T) == 8 && cc < 3;") == 2 and s.count("(T) == 0 && cc > 0;") == 2
     # grouped form (R4_TILE): L(2t+2) at the start of phase A, L(2t+3) between the two MFMA groups of phase B
     assert re.search(r"R4_LOADW\(SNX_\);[^\n]*\n\s*R4_READ_A\(0, T\);", s)
     assert "if (restaged_) R4_VMWAIT_LATE(8);" in s and "else R4_VMWAITW(8);" in s

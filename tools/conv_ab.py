@@ -92,7 +92,7 @@ def main():
         outs[name] = y.clone()
     # ablation arms (variant bits >= 16: no MFMAs / no fragment reads / no weight staging / no barriers) time a kernel whose
     # results are wrong by construction
-    ablation = lambda mode: not isinstance(mode, tuple) and ((mode >= 16 and ((mode - 16) & (16 | 32 | 64 | 128 | 2048)) != 0) or (mode < 0 and ((-mode - 1) & (4 | 32 | 64)) != 0))
+    ablation = lambda mode: not isinstance(mode, tuple) and ((mode >= 16 and ((mode - 16) & (16 | 32 | 64 | 128 | 2048)) != 0) or (mode < 0 and ((-mode - 1) & (4 | 32 | 64 | 128)) != 0))
     assert all(torch.equal(outs[arms[0][0]], o) for (name, mode), o in zip(arms, outs.values()) if not ablation(mode)), "an arm changed the result"
     for _ in range(10):
         run()
