@@ -471,14 +471,16 @@ def test_distributed_selfplay_gathers_tuples_to_rank0(tmp_path, world, backend):
 
 
 @pytest.mark.gpu
-def test_bench_stdout_is_one_json_line():
+@pytest.mark.parametrize("tower", [-1, 2], ids=["default_tower", "packed_tower"])
+def test_bench_stdout_is_one_json_line(tower):
     """The driver reads ONE JSON line from bench.py's stdout: whatever libraries print from C (RCCL's banner) must not land
     there.  Small configuration (9x9, the real 256-channel tower with enough launches for the 1-in-16 sampled
     launch timing, so the roofline object names the tower kernel)."""
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--size", "9", "--games", "64", "--sims", "64", "--blocks", "4",
-                        "--steps", "1", "--warmup", "1", "--cpu-baseline", "0", "--saturated", "0", "--steady-state", "0"],
+                        "--steps", "1", "--warmup", "1", "--cpu-baseline", "0", "--saturated", "0", "--steady-state", "0",
+                        "--tower-kernel", str(tower)],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     lines = r.stdout.decode().splitlines()
@@ -488,4 +490,5 @@ def test_bench_stdout_is_one_json_line():
               "dtype", "data", "config", "roofline"):
         assert k in out, k
     assert out["n_gpus"] == 1 and out["steps"] == 1 and out["value"] > 0
-    assert "k_conv4w" in out["roofline"]["kernel"] and 0 < out["roofline"]["frac"] < 1
+    # bench.py --tower-kernel 2 runs the step on k_conv4r (net.use_packed_tower) and says so in the roofline object
+    assert ("k_conv4r" if tower == 2 else "k_conv4w") in out["roofline"]["kernel"] and 0 < out["roofline"]["frac"] < 1
