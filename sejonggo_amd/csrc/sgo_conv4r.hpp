@@ -19,6 +19,13 @@
 //   phase B: read pixel-hi fragments | 16 MFMA lo | issue L(2t+3) (set of lo(t), dead from here) | 16 MFMA hi
 // A wave issues exactly eight weight loads per K-tile, so the counted waits are vmcnt(8) / vmcnt(4); chunk boundaries add the
 // window pieces (see R4_TILE).  The last K-tile's two look-ahead loads read the 8 KB of padding behind the packed bank.
+//
+// RESULT (round 3, profiles/r03_conv4r_experiment.json): identical bits, and the same speed as k_conv4w within 1 % on every box
+// (2.10-2.20 ms per 8 192 x 17 x 17 launch, 0.52 of the fp16 MFMA peak), wherever the loads are issued.  The route saves cycles
+// (LDS instruction cycles -29 %, kernel cycles -0.8 %) and pays them back in clock: the chip is power-limited under this kernel,
+// and 64 KB per K-tile pair through the vector-memory path costs frequency even though the duplicates hit in L1
+// (profiles/r03_pmc_conv4r_ablate.json: the weight loads are 5 % of the cycles and 16 % of the time; the pixel reads 13 % / 16 %).
+// It is kept as a selectable route (sgo_conv3x3_tower_packed_dev), not as the default.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -55,7 +62,9 @@ constexpr int LW = 0, LZ = 40960, LZ_BYTES = 3 * 2048 + 256, LDS_BYTES = 65536;
     __builtin_amdgcn_sched_barrier(0)
 
 // VAR bit 0: s_setprio(1) around the MFMA bursts; bit 1: the look-ahead load of hi(t+1) is issued at the END of phase B instead
-// of between its two MFMA groups.  ABLATION bits (timing only, wrong results; -DSGO_CONV4W_VARIANTS builds): 4 no weight loads, 32 no window DMA in the prologue, 64 no pixel fragment reads, 128 no restage (and no barrier) at the chunk boundaries.
+// of between its two MFMA groups; bit 4 (16): the loads spread inside the bursts (R4_TILE_S).  ABLATION bits (timing only, wrong
+// results; -DSGO_CONV4W_VARIANTS builds): 4 no weight loads, 32 no window DMA in the prologue, 64 no pixel fragment reads, 128 no
+// restage (and no barrier) at the chunk boundaries.
 // Measured and dropped (round 3): a DOUBLE-BUFFERED window for board widths <= 17 (two 292-row buffers + the zero area = 81 152 B,
 // two workgroups per CU still fit; the next chunk's pieces staged two per tap at the start of taps 0..4 with the lanes beyond the
 // window masked off, ONE barrier per chunk boundary, no drain): bit-identical, 252 VGPRs, and 3.2 % SLOWER (2.180 vs 2.112 ms in
